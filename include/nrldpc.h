@@ -1,0 +1,106 @@
+/*
+ * nrldpc.h -- C ABI of the MI355X-native NR LDPC codec core (libnrldpc_hip.so).
+ *
+ * Drop-in boundary for the one hot path of robmaunder/ldpc-3gpp-matlab: the LDPC coding core that
+ * the reference's System objects delegate to MathWorks toolbox objects.
+ *
+ *   nrldpc_create   replaces  comm.LDPCDecoder('ParityCheckMatrix',H,'MaximumIterationCount',it,
+ *                             'IterationTerminationCondition','Parity check satisfied')
+ *                             NRLDPCDecoder.m:120 (and the commented-out comm.gpu.LDPCDecoder seam at
+ *                             :117-121), and comm.LDPCEncoder('ParityCheckMatrix',H) NRLDPCEncoder.m:49.
+ *                             H is never materialised: (bg, Z) identify it (NRLDPC.m:433-440,
+ *                             get_3gpp_base_graph.m, get_pcm.m).
+ *   nrldpc_decode   replaces  step(obj.hLDPCDecoder, cw_tilde)   NRLDPCDecoder.m:265
+ *   nrldpc_encode   replaces  step(obj.hLDPCEncoder, c)          NRLDPCEncoder.m:158
+ *   nrldpc_destroy  replaces  release() of those toolbox objects
+ *
+ * Plain pointers and sizes only.  Host-pointer entry points are synchronous; *_dev entry points take
+ * device pointers plus a hipStream_t (passed as void*) and are asynchronous on that stream.
+ * A handle is not thread-safe; use one handle per GPU / host thread.
+ *
+ * Error convention (NRLDPC.m / NRLDPCDecoder.m use two MATLAB identifiers; the MEX gateway maps
+ * return codes onto exactly those):
+ *   NRLDPC_ERR_UNSUPPORTED -> 'ldpc_3gpp_matlab:UnsupportedParameters'  (callers catch and skip:
+ *                             plot_BLER_vs_SNR.m:173, testbench.m:51)
+ *   NRLDPC_ERR_ARG / _HIP  -> 'ldpc_3gpp_matlab:Error'                  (e.g. NRLDPCDecoder.m:149)
+ */
+#ifndef NRLDPC_H
+#define NRLDPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRLDPC_OK 0
+#define NRLDPC_ERR_UNSUPPORTED 1 /* invalid BG / lifting size / layer count / parameter combination */
+#define NRLDPC_ERR_ARG 2         /* shape or pointer violation */
+#define NRLDPC_ERR_HIP 3         /* HIP runtime failure (text via nrldpc_last_error) */
+#define NRLDPC_ERR_NOMEM 4
+
+/* LLR element types accepted at the boundary.  Codeword-contiguous layout [batch][ncols*Z], which
+ * is MATLAB's column-major (ncols*Z) x batch.  Positive LLR <=> bit 0 (NRLDPCDecoder.m:262-266):
+ * 0 = punctured / untransmitted, +inf = filler bit (known 0). */
+#define NRLDPC_LLR_F32 0
+#define NRLDPC_LLR_F16 1
+#define NRLDPC_LLR_F64 2 /* host entry point only (MATLAB double); narrowed to f32 on the host */
+
+typedef struct nrldpc_codec* nrldpc_handle;
+
+typedef struct nrldpc_cfg {
+    int32_t bg;         /* 1 or 2                                     (NRLDPC.m:28)               */
+    int32_t Z;          /* lifting size Z_c, one of the 51 of Table 5.3.2-1 (NRLDPC.m:409-411)    */
+    int32_t n_layers;   /* base rows to decode, 4..46 (BG1) / 4..42 (BG2); 0 = all (reference: all) */
+    int32_t max_iter;   /* 'MaximumIterationCount' (NRLDPCDecoder.m:41,120); 1..2000              */
+    int32_t early_term; /* 1 = stop a codeword when all active parity checks hold (reference: 1)  */
+    float alpha;        /* min-sum normalisation factor, 0 < alpha <= 1; 0 selects the default 0.75 */
+    int32_t llr_scale;  /* fixed-point units per unit LLR: 4, 8 or 16; 0 selects the default 8    */
+    int32_t llr_dtype;  /* NRLDPC_LLR_*                                                            */
+    int32_t device_id;  /* HIP device ordinal                                                      */
+    int32_t max_batch;  /* staging capacity of the host entry points; 0 = grow on demand          */
+} nrldpc_cfg;
+
+/* Dimensions implied by (bg, Z): ncols*Z LLRs in, K = kb*Z hard bits out. */
+typedef struct nrldpc_dims {
+    int32_t nrows, ncols, kb; /* 46,68,22 or 42,52,10 */
+    int32_t i_ls;             /* set index (get_3gpp_set_index.m) */
+    int32_t K, N_cw;          /* kb*Z, ncols*Z */
+    int32_t n_layers;         /* resolved active layer count */
+} nrldpc_dims;
+
+int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out);
+void nrldpc_destroy(nrldpc_handle h);
+int nrldpc_get_dims(nrldpc_handle h, nrldpc_dims* out);
+
+/* Decode `batch` codewords.  llr: [batch][ncols*Z] of cfg.llr_dtype.  hard: [batch][K] bytes in
+ * {0,1} (the K x 1 logical of comm.LDPCDecoder).  iters_out (nullable): iterations executed per
+ * codeword.  app_out (nullable): a-posteriori LLRs [batch][ncols*Z] float. */
+int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out,
+                  float* app_out);
+int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t* d_hard,
+                      int32_t* d_iters_out, float* d_app_out, void* stream);
+
+/* Systematic encode.  info: [batch][K] bytes {0,1}; cw: [batch][ncols*Z] bytes {0,1} = [info;parity]
+ * with H*cw = 0 (NRLDPCEncoder.m:158). */
+int nrldpc_encode(nrldpc_handle h, const uint8_t* info, int32_t batch, uint8_t* cw);
+int nrldpc_encode_dev(nrldpc_handle h, const uint8_t* d_info, int32_t batch, uint8_t* d_cw, void* stream);
+
+/* Kernel timing: when enabled, every *_dev / host call records HIP events around its kernel on the
+ * launch stream; nrldpc_last_kernel_ms synchronises on the stop event and returns the duration. */
+int nrldpc_set_timing(nrldpc_handle h, int32_t enabled);
+int nrldpc_last_kernel_ms(nrldpc_handle h, float* ms);
+
+/* Parameter helpers shared with the host-side chain (no device work). */
+int nrldpc_set_index(int32_t Z);                        /* get_3gpp_set_index.m:5-11; -1 if invalid  */
+int nrldpc_lifting_size(int32_t K_b, int32_t K_prime);  /* get_3gpp_lifting_size.m:5-16; -1 if none */
+
+const char* nrldpc_strerror(int code);
+const char* nrldpc_last_error(void); /* text of the most recent failure on this thread */
+const char* nrldpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRLDPC_H */

@@ -1,0 +1,179 @@
+"""ctypes binding of the C ABI declared in include/nrldpc.h (libnrldpc_hip.so).
+
+There is no CPU implementation behind this module: if the shared object is missing it is built
+with hipcc; if that is impossible, import fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OK, ERR_UNSUPPORTED, ERR_ARG, ERR_HIP, ERR_NOMEM = 0, 1, 2, 3, 4
+LLR_F32, LLR_F16, LLR_F64 = 0, 1, 2
+
+
+class UnsupportedParameters(ValueError):
+    """Mirror of the MATLAB identifier 'ldpc_3gpp_matlab:UnsupportedParameters'
+    (e.g. NRLDPC.m:240-294, get_3gpp_set_index.m:10)."""
+    identifier = "ldpc_3gpp_matlab:UnsupportedParameters"
+
+
+class NRLDPCError(RuntimeError):
+    """Mirror of the MATLAB identifier 'ldpc_3gpp_matlab:Error' (e.g. NRLDPCDecoder.m:149)."""
+    identifier = "ldpc_3gpp_matlab:Error"
+
+
+class Cfg(C.Structure):
+    _fields_ = [("bg", C.c_int32), ("Z", C.c_int32), ("n_layers", C.c_int32), ("max_iter", C.c_int32),
+                ("early_term", C.c_int32), ("alpha", C.c_float), ("llr_scale", C.c_int32),
+                ("llr_dtype", C.c_int32), ("device_id", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class Dims(C.Structure):
+    _fields_ = [("nrows", C.c_int32), ("ncols", C.c_int32), ("kb", C.c_int32), ("i_ls", C.c_int32),
+                ("K", C.c_int32), ("N_cw", C.c_int32), ("n_layers", C.c_int32)]
+
+
+EXPORTS = ["nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
+           "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
+           "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_strerror", "nrldpc_last_error",
+           "nrldpc_version"]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building first if needed) libnrldpc_hip.so.  Raises if it cannot be produced."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        path = _build.build_lib()
+    L = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.nrldpc_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
+    L.nrldpc_destroy.argtypes = [vp]
+    L.nrldpc_destroy.restype = None
+    L.nrldpc_get_dims.argtypes = [vp, C.POINTER(Dims)]
+    L.nrldpc_decode.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.nrldpc_decode_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.nrldpc_encode.argtypes = [vp, vp, i32, vp]
+    L.nrldpc_encode_dev.argtypes = [vp, vp, i32, vp, vp]
+    L.nrldpc_set_timing.argtypes = [vp, i32]
+    L.nrldpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.nrldpc_set_index.argtypes = [i32]
+    L.nrldpc_lifting_size.argtypes = [i32, i32]
+    for f in ("nrldpc_strerror", "nrldpc_last_error", "nrldpc_version"):
+        getattr(L, f).restype = C.c_char_p
+    L.nrldpc_strerror.argtypes = [i32]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc == OK:
+        return
+    L = load()
+    msg = (L.nrldpc_last_error() or b"").decode() or L.nrldpc_strerror(rc).decode()
+    if rc == ERR_UNSUPPORTED:
+        raise UnsupportedParameters(msg)
+    raise NRLDPCError(msg)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_NP2DT = {np.dtype(np.float32): LLR_F32, np.dtype(np.float16): LLR_F16, np.dtype(np.float64): LLR_F64}
+
+
+class Codec:
+    """One (BG, Z) LDPC coding core on one GPU: the object that takes the place of
+    comm.LDPCDecoder / comm.LDPCEncoder in the reference (NRLDPCDecoder.m:120, NRLDPCEncoder.m:49)."""
+
+    def __init__(self, bg, Z, max_iter=50, n_layers=0, early_term=True, alpha=0.0, llr_scale=0,
+                 llr_dtype=np.float32, device_id=0, max_batch=0):
+        L = load()
+        self._lib = L
+        self._h = C.c_void_p()
+        self.llr_dtype = np.dtype(llr_dtype)
+        cfg = Cfg(int(bg), int(Z), int(n_layers), int(max_iter), int(bool(early_term)), float(alpha),
+                  int(llr_scale), _NP2DT[self.llr_dtype], int(device_id), int(max_batch))
+        check(L.nrldpc_create(C.byref(cfg), C.byref(self._h)))
+        d = Dims()
+        check(L.nrldpc_get_dims(self._h, C.byref(d)))
+        self.bg, self.Z = int(bg), int(Z)
+        self.K, self.N_cw, self.kb, self.ncols, self.nrows = d.K, d.N_cw, d.kb, d.ncols, d.nrows
+        self.i_ls, self.n_layers = d.i_ls, d.n_layers
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.nrldpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-pointer entry points (numpy arrays) -------------------------------------------------
+    def decode(self, llr, want_iters=False, want_app=False):
+        llr = np.ascontiguousarray(llr, self.llr_dtype)
+        if llr.size % self.N_cw:
+            raise NRLDPCError("llr should hold a whole number of codewords of length %d" % self.N_cw)
+        B = llr.size // self.N_cw
+        hard = np.empty((B, self.K), np.uint8)
+        iters = np.empty(B, np.int32) if want_iters else None
+        app = np.empty((B, self.N_cw), np.float32) if want_app else None
+        check(self._lib.nrldpc_decode(self._h, _ptr(llr), B, _ptr(hard), _ptr(iters), _ptr(app)))
+        out = (hard,)
+        if want_iters:
+            out += (iters,)
+        if want_app:
+            out += (app,)
+        return out[0] if len(out) == 1 else out
+
+    def encode(self, info):
+        info = np.ascontiguousarray(info, np.uint8)
+        if info.size % self.K:
+            raise NRLDPCError("info should hold a whole number of blocks of length %d" % self.K)
+        B = info.size // self.K
+        cw = np.empty((B, self.N_cw), np.uint8)
+        check(self._lib.nrldpc_encode(self._h, _ptr(info), B, _ptr(cw)))
+        return cw
+
+    # -- device-pointer entry points (raw addresses, e.g. torch.Tensor.data_ptr()) ----------------
+    def decode_dev(self, d_llr, batch, d_hard, d_iters=None, d_app=None, stream=0):
+        check(self._lib.nrldpc_decode_dev(self._h, _ptr(d_llr), int(batch), _ptr(d_hard), _ptr(d_iters),
+                                          _ptr(d_app), C.c_void_p(stream)))
+
+    def encode_dev(self, d_info, batch, d_cw, stream=0):
+        check(self._lib.nrldpc_encode_dev(self._h, _ptr(d_info), int(batch), _ptr(d_cw), C.c_void_p(stream)))
+
+    def set_timing(self, on=True):
+        check(self._lib.nrldpc_set_timing(self._h, int(on)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(self._lib.nrldpc_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+
+def set_index(Z):
+    return load().nrldpc_set_index(int(Z))
+
+
+def lifting_size(K_b, K_prime):
+    return load().nrldpc_lifting_size(int(K_b), int(K_prime))

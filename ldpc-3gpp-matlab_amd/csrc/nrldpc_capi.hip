@@ -1,0 +1,341 @@
+// nrldpc_capi.hip -- the C ABI of include/nrldpc.h over the gfx950 kernels.
+//
+// Host-pointer entry points stage through device buffers owned by the handle; *_dev entry points
+// launch directly on caller-owned device memory.  No CPU fallback exists anywhere in this library:
+// every decode/encode is a HIP kernel launch, and any HIP failure is reported as NRLDPC_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nrldpc.h"
+#include "nrldpc_kernels.h"
+#include "nrldpc_sched.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hipfail(hipError_t e, const char* what) {
+    return fail(NRLDPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return hipfail(_e, #expr); \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t reserve(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+} // namespace
+
+struct nrldpc_codec {
+    nrldpc_cfg cfg;
+    nrldpc::Schedule sched;
+    float alpha = 0.75f;
+    int scale = 8;
+    // device tables
+    DevBuf<int32_t> d_rot;
+    DevBuf<uint16_t> d_row_ptr, d_shift;
+    DevBuf<uint8_t> d_col;
+    // encoder solve order
+    int p0_shift = 0, step_row[3] = {0, 0, 0}, step_col[3] = {0, 0, 0}, step_shift[3] = {0, 0, 0};
+    // host-entry staging
+    DevBuf<char> s_llr;
+    DevBuf<uint8_t> s_hard, s_bits;
+    DevBuf<int32_t> s_iters;
+    DevBuf<float> s_app;
+    std::vector<float> h_narrow;
+    // timing
+    bool timing = false, have_time = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+size_t llr_elem_bytes(int dtype) { return dtype == NRLDPC_LLR_F16 ? 2 : 4; }
+
+// Substitution order for the core-parity blocks (same derivation as the oracle's encode_one, from the
+// dual-diagonal entries at get_3gpp_base_graph.m:30-31,48-50,68-69,87-88 / :339-340,349-350,356-358,367-368).
+bool derive_encoder_order(nrldpc_codec* h) {
+    const nrldpc::Schedule& s = h->sched;
+    const nrldpc::BaseGraph& g = s.g;
+    const int kb = g.kb;
+    int cnt[4] = {0, 0, 0, 0}, sh0[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+        for (int e = g.row_ptr[i]; e < g.row_ptr[i + 1]; ++e)
+            if (g.col[e] == kb) { cnt[i] = 1; sh0[i] = s.shift[e]; }
+    int a = -1;
+    for (int i = 0; i < 4; ++i) {
+        if (!cnt[i]) continue;
+        int n = 0;
+        for (int k = 0; k < 4; ++k) n += (cnt[k] && sh0[k] == sh0[i]);
+        if (n & 1) a = sh0[i];
+    }
+    if (a < 0) return false;
+    h->p0_shift = a;
+    bool known[4] = {true, false, false, false};
+    for (int st = 0; st < 3; ++st) {
+        bool found = false;
+        for (int i = 0; i < 4 && !found; ++i) {
+            int unk = -1, nunk = 0, ush = 0;
+            for (int e = g.row_ptr[i]; e < g.row_ptr[i + 1]; ++e) {
+                int c = g.col[e] - kb;
+                if (c >= 0 && c < 4 && !known[c]) { unk = c; ush = s.shift[e]; ++nunk; }
+            }
+            if (nunk == 1) {
+                h->step_row[st] = i; h->step_col[st] = unk; h->step_shift[st] = ush;
+                known[unk] = true; found = true;
+            }
+        }
+        if (!found) return false;
+    }
+    return true;
+}
+
+void begin_timing(nrldpc_codec* h, hipStream_t s) {
+    if (h->timing) (void)hipEventRecord(h->ev0, s);
+}
+void end_timing(nrldpc_codec* h, hipStream_t s) {
+    if (h->timing) { (void)hipEventRecord(h->ev1, s); h->have_time = true; }
+}
+
+int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters, float* d_app,
+                  hipStream_t stream) {
+    const nrldpc::Schedule& s = h->sched;
+    nrldpc::DecArgs a;
+    a.llr = d_llr; a.hard = d_hard; a.iters = d_iters; a.app = d_app;
+    a.rot = h->d_rot.p;
+    a.batch = batch; a.Z = s.Z; a.n_layers = s.n_layers; a.max_iter = h->cfg.max_iter; a.ncw = s.ncw; a.sbw = s.sbw;
+    a.early_term = h->cfg.early_term ? 1 : 0;
+    a.need_ext = (a.early_term || d_app) ? 1 : 0;
+    a.llr_kind = (h->cfg.llr_dtype == NRLDPC_LLR_F16) ? NRLDPC_K_F16 : NRLDPC_K_F32;
+    a.alpha = h->alpha; a.scale = (float)h->scale; a.inv_scale = 1.0f / (float)h->scale;
+    begin_timing(h, stream);
+    hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, stream);
+    end_timing(h, stream);
+    if (e != hipSuccess) return hipfail(e, "decode kernel launch");
+    return NRLDPC_OK;
+}
+
+int encode_launch(nrldpc_codec* h, const uint8_t* d_info, int batch, uint8_t* d_cw, hipStream_t stream) {
+    const nrldpc::Schedule& s = h->sched;
+    nrldpc::EncArgs a;
+    a.info = d_info; a.cw = d_cw;
+    a.row_ptr = h->d_row_ptr.p; a.col = h->d_col.p; a.shift = h->d_shift.p;
+    a.batch = batch; a.Z = s.Z; a.nrows = s.g.nrows; a.ncols = s.g.ncols; a.kb = s.g.kb;
+    a.p0_shift = h->p0_shift;
+    for (int i = 0; i < 3; ++i) { a.step_row[i] = h->step_row[i]; a.step_col[i] = h->step_col[i]; a.step_shift[i] = h->step_shift[i]; }
+    begin_timing(h, stream);
+    hipError_t e = nrldpc::launch_encode(a, stream);
+    end_timing(h, stream);
+    if (e != hipSuccess) return hipfail(e, "encode kernel launch");
+    return NRLDPC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int nrldpc_set_index(int32_t Z) { return nrldpc::set_index(Z); }
+int nrldpc_lifting_size(int32_t K_b, int32_t K_prime) { return nrldpc::lifting_size(K_b, K_prime); }
+
+const char* nrldpc_strerror(int code) {
+    switch (code) {
+        case NRLDPC_OK: return "ok";
+        case NRLDPC_ERR_UNSUPPORTED: return "unsupported parameters";
+        case NRLDPC_ERR_ARG: return "invalid argument";
+        case NRLDPC_ERR_HIP: return "HIP runtime error";
+        case NRLDPC_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+const char* nrldpc_last_error(void) { return g_err.c_str(); }
+const char* nrldpc_version(void) { return "nrldpc-hip 0.1 (gfx950)"; }
+
+int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
+    if (!cfg || !out) return fail(NRLDPC_ERR_ARG, "null cfg/out");
+    *out = nullptr;
+    if (cfg->bg != 1 && cfg->bg != 2) return fail(NRLDPC_ERR_UNSUPPORTED, "BG must be 1 or 2");
+    if (nrldpc::set_index(cfg->Z) < 0) return fail(NRLDPC_ERR_UNSUPPORTED, "Invalid lifting size.");
+    if (cfg->max_iter < 1 || cfg->max_iter > 2000) return fail(NRLDPC_ERR_UNSUPPORTED, "max_iter must be in 1..2000");
+    if (cfg->llr_dtype < NRLDPC_LLR_F32 || cfg->llr_dtype > NRLDPC_LLR_F64)
+        return fail(NRLDPC_ERR_UNSUPPORTED, "unknown llr_dtype");
+    float alpha = cfg->alpha == 0.0f ? 0.75f : cfg->alpha;
+    if (!(alpha > 0.0f && alpha <= 1.0f)) return fail(NRLDPC_ERR_UNSUPPORTED, "alpha must be in (0,1]");
+    int scale = cfg->llr_scale == 0 ? 8 : cfg->llr_scale;
+    if (scale != 1 && scale != 2 && scale != 4 && scale != 8 && scale != 16 && scale != 32)
+        return fail(NRLDPC_ERR_UNSUPPORTED, "llr_scale must be a power of two in 1..32");
+    nrldpc_codec* h = new (std::nothrow) nrldpc_codec();
+    if (!h) return fail(NRLDPC_ERR_NOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->alpha = alpha;
+    h->scale = scale;
+    if (!nrldpc::build_schedule(cfg->bg, cfg->Z, cfg->n_layers, &h->sched)) {
+        delete h;
+        return fail(NRLDPC_ERR_UNSUPPORTED, "n_layers must be 0 or in 4..rows of the base graph");
+    }
+    if (!derive_encoder_order(h)) {
+        delete h;
+        return fail(NRLDPC_ERR_UNSUPPORTED, "base graph core is not dual-diagonal");
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        delete h;
+        return fail(NRLDPC_ERR_HIP, "no HIP device available (this library has no CPU path)");
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) {
+        delete h;
+        return fail(NRLDPC_ERR_ARG, "device_id out of range");
+    }
+#define CREATE_TRY(expr)                                                  \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) { int rc = hipfail(_e, #expr); nrldpc_destroy(h); return rc; } \
+    } while (0)
+    CREATE_TRY(hipSetDevice(cfg->device_id));
+    const nrldpc::Schedule& s = h->sched;
+    CREATE_TRY(h->d_rot.reserve(s.rot.size()));
+    CREATE_TRY(hipMemcpy(h->d_rot.p, s.rot.data(), s.rot.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint16_t> sh16(s.shift.begin(), s.shift.end());
+    CREATE_TRY(h->d_row_ptr.reserve(s.g.nrows + 1));
+    CREATE_TRY(h->d_col.reserve(s.g.nnz));
+    CREATE_TRY(h->d_shift.reserve(s.g.nnz));
+    CREATE_TRY(hipMemcpy(h->d_row_ptr.p, s.g.row_ptr, (s.g.nrows + 1) * 2, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_col.p, s.g.col, s.g.nnz, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_shift.p, sh16.data(), s.g.nnz * 2, hipMemcpyHostToDevice));
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+#undef CREATE_TRY
+    *out = h;
+    return NRLDPC_OK;
+}
+
+void nrldpc_destroy(nrldpc_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    h->d_rot.release();
+    h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
+    h->s_llr.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+int nrldpc_get_dims(nrldpc_handle h, nrldpc_dims* out) {
+    if (!h || !out) return fail(NRLDPC_ERR_ARG, "null handle/out");
+    const nrldpc::Schedule& s = h->sched;
+    out->nrows = s.g.nrows; out->ncols = s.g.ncols; out->kb = s.g.kb; out->i_ls = s.ils;
+    out->K = s.g.kb * s.Z; out->N_cw = s.g.ncols * s.Z; out->n_layers = s.n_layers;
+    return NRLDPC_OK;
+}
+
+int nrldpc_set_timing(nrldpc_handle h, int32_t enabled) {
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    h->timing = enabled != 0;
+    h->have_time = false;
+    return NRLDPC_OK;
+}
+
+int nrldpc_last_kernel_ms(nrldpc_handle h, float* ms) {
+    if (!h || !ms) return fail(NRLDPC_ERR_ARG, "null handle/out");
+    if (!h->timing || !h->have_time) return fail(NRLDPC_ERR_ARG, "no timed launch recorded");
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return NRLDPC_OK;
+}
+
+int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t* d_hard, int32_t* d_iters_out,
+                      float* d_app_out, void* stream) {
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (batch == 0) return NRLDPC_OK;
+    if (!d_llr || !d_hard) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
+    if (h->cfg.llr_dtype == NRLDPC_LLR_F64) return fail(NRLDPC_ERR_ARG, "f64 LLRs are accepted by the host entry point only");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    return decode_launch(h, d_llr, batch, d_hard, d_iters_out, d_app_out, static_cast<hipStream_t>(stream));
+}
+
+int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out) {
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (batch == 0) return NRLDPC_OK;
+    if (!llr || !hard) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const nrldpc::Schedule& s = h->sched;
+    const size_t ncw = (size_t)s.g.ncols * s.Z, K = (size_t)s.g.kb * s.Z;
+    const size_t cap = (h->cfg.max_batch > batch) ? (size_t)h->cfg.max_batch : (size_t)batch;
+    const void* src = llr;
+    size_t eb = llr_elem_bytes(h->cfg.llr_dtype);
+    if (h->cfg.llr_dtype == NRLDPC_LLR_F64) { // MATLAB doubles: narrow on the host (halves PCIe bytes)
+        h->h_narrow.resize((size_t)batch * ncw);
+        const double* d = static_cast<const double*>(llr);
+        for (size_t i = 0; i < (size_t)batch * ncw; ++i) h->h_narrow[i] = (float)d[i];
+        src = h->h_narrow.data();
+        eb = 4;
+    }
+    HIP_TRY(h->s_llr.reserve(cap * ncw * eb));
+    HIP_TRY(h->s_hard.reserve(cap * K));
+    if (iters_out) HIP_TRY(h->s_iters.reserve(cap));
+    if (app_out) HIP_TRY(h->s_app.reserve(cap * ncw));
+    HIP_TRY(hipMemcpyAsync(h->s_llr.p, src, (size_t)batch * ncw * eb, hipMemcpyHostToDevice, nullptr));
+    // F64 was narrowed to f32 above; the kernel sees f32 in that case.
+    int rc = decode_launch(h, h->s_llr.p, batch, h->s_hard.p, iters_out ? h->s_iters.p : nullptr,
+                           app_out ? h->s_app.p : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(hard, h->s_hard.p, (size_t)batch * K, hipMemcpyDeviceToHost, nullptr));
+    if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, h->s_iters.p, (size_t)batch * 4, hipMemcpyDeviceToHost, nullptr));
+    if (app_out) HIP_TRY(hipMemcpyAsync(app_out, h->s_app.p, (size_t)batch * ncw * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NRLDPC_OK;
+}
+
+int nrldpc_encode_dev(nrldpc_handle h, const uint8_t* d_info, int32_t batch, uint8_t* d_cw, void* stream) {
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (batch == 0) return NRLDPC_OK;
+    if (!d_info || !d_cw) return fail(NRLDPC_ERR_ARG, "null info/cw pointer");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    return encode_launch(h, d_info, batch, d_cw, static_cast<hipStream_t>(stream));
+}
+
+int nrldpc_encode(nrldpc_handle h, const uint8_t* info, int32_t batch, uint8_t* cw) {
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (batch == 0) return NRLDPC_OK;
+    if (!info || !cw) return fail(NRLDPC_ERR_ARG, "null info/cw pointer");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const nrldpc::Schedule& s = h->sched;
+    const size_t ncw = (size_t)s.g.ncols * s.Z, K = (size_t)s.g.kb * s.Z;
+    HIP_TRY(h->s_bits.reserve((size_t)batch * K));
+    HIP_TRY(h->s_hard.reserve((size_t)batch * ncw));
+    HIP_TRY(hipMemcpyAsync(h->s_bits.p, info, (size_t)batch * K, hipMemcpyHostToDevice, nullptr));
+    int rc = encode_launch(h, h->s_bits.p, batch, h->s_hard.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(cw, h->s_hard.p, (size_t)batch * ncw, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NRLDPC_OK;
+}
+
+} // extern "C"

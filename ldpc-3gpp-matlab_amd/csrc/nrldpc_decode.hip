@@ -1,0 +1,351 @@
+// nrldpc_decode.hip -- layered normalised-min-sum NR LDPC decoder for gfx950 (MI355X / CDNA4).
+//
+// Replaces the inner loop of the reference's decode path: step(obj.hLDPCDecoder, cw_tilde) at
+// NRLDPCDecoder.m:265 (object constructed at :120).  Algorithm "NMS-Q" as restated in
+// oracle/nrldpc_oracle.c (orc_decode_nmsq); the two must agree bit for bit.
+//
+// Mapping (CDNA4-first, not a streaming design):
+//   * one workgroup owns `ncw` whole codewords for ALL iterations; thread (cwl, z) owns check row z of
+//     every base-graph layer of codeword cwl (Z = 384 -> 6 wave64 per codeword, ncw = 1);
+//   * a-posteriori LLRs of the kb+4 core columns live in LDS for the whole decode, ring-position
+//     major with an odd dword stride (bank-conflict free for ds_read_b32/ds_write_b32 at unit
+//     position stride); check row z reads and writes ring position (z + P) mod Z of each of its
+//     columns: three VALU ops per edge (add, add, v_min_u32 -- the unsigned-underflow trick), the
+//     column offset rides in the ds instruction's immediate, and every LDS word is touched by exactly
+//     one thread per layer, so one barrier per layer suffices;
+//   * check-to-variable messages live in VGPRs as int8 (4 per register, SDWA byte convert/insert);
+//   * channel LLRs of the degree-1 extension-parity columns never enter LDS: such a column is only
+//     ever touched by its own row at ring position z, so it is thread-private (int8 in VGPRs);
+//   * all values are integers carried in fp32 (exact below 2^24), so abs/neg modifiers, v_med3_f32
+//     and v_min_f32 do the min-sum in 8 VALU ops per edge for pass 1 and 7 for pass 2.
+// HBM sees each codeword once on the way in (ncols*Z LLRs) and K hard bits on the way out.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "nr_bg_tables.h"
+#include "nrldpc_kernels.h"
+
+namespace nrldpc {
+
+template <int BG> struct BGT;
+template <> struct BGT<1> {
+    static constexpr int ROWS = NR_BG1_ROWS, COLS = NR_BG1_COLS, KB = 22, NNZ = NR_BG1_NNZ;
+    static constexpr int row_ptr(int r) { return nr_bg1_row_ptr[r]; }
+    static constexpr int col(int e) { return nr_bg1_col[e]; }
+};
+template <> struct BGT<2> {
+    static constexpr int ROWS = NR_BG2_ROWS, COLS = NR_BG2_COLS, KB = 10, NNZ = NR_BG2_NNZ;
+    static constexpr int row_ptr(int r) { return nr_bg2_row_ptr[r]; }
+    static constexpr int col(int e) { return nr_bg2_col[e]; }
+};
+template <int BG> struct BGD : BGT<BG> {
+    static constexpr int NC = BGT<BG>::KB + 4;                    // core columns (LDS resident)
+    static constexpr int NCP = NC | 1;                            // odd dword stride
+    static constexpr int NEXT = BGT<BG>::ROWS - 4;                // extension rows / columns
+    static constexpr int NCORE = BGT<BG>::NNZ - NEXT;             // core edges (messages stored)
+    static constexpr int NW = (NCORE + 3) / 4;                    // message registers
+    static constexpr int NXW = (NEXT + 3) / 4;                    // extension-LLR registers
+    // number of core edges before row L (every row >= 4 carries exactly one extension edge, last)
+    static constexpr int core_base(int L) { return BGT<BG>::row_ptr(L) - (L > 4 ? L - 4 : 0); }
+};
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __float_as_uint(x); }
+
+// Schedule tables are read through the constant address space so that every access is a scalar
+// (s_load) instruction: the index is compile-time, the base wave-uniform.
+typedef const int32_t __attribute__((address_space(4))) * ctab_t;
+__device__ __forceinline__ ctab_t as_ctab(const int32_t* p) { return reinterpret_cast<ctab_t>(reinterpret_cast<uintptr_t>(p)); }
+// Opaque identity on a wave-uniform value: stops LLVM hoisting iteration-invariant scalar loads,
+// write addresses and layer predicates out of the iteration loop (which costs >230 VGPRs + SGPR spills).
+__device__ __forceinline__ ctab_t launder(ctab_t p) {
+    uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    asm volatile("" : "+s"(v));
+    return reinterpret_cast<ctab_t>(v);
+}
+__device__ __forceinline__ int launder(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// signed byte B of w -> float (one SDWA VALU op)
+template <int B> __device__ __forceinline__ float byte_to_f32(uint32_t w) {
+    float f;
+    if constexpr (B == 0)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(f) : "v"(w));
+    else if constexpr (B == 1)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(f) : "v"(w));
+    else if constexpr (B == 2)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f) : "v"(w));
+    else
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(f) : "v"(w));
+    return f;
+}
+// (int)r -> byte B of w, other bytes preserved (one SDWA VALU op); r is an integer-valued float in [-127,127]
+template <int B> __device__ __forceinline__ void f32_to_byte(uint32_t& w, float r) {
+    if constexpr (B == 0)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
+    else if constexpr (B == 1)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
+    else if constexpr (B == 2)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
+    else
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
+}
+
+template <int DT> __device__ __forceinline__ float load_llr(const void* p, size_t i) {
+    if constexpr (DT == NRLDPC_K_F16)
+        return __half2float(static_cast<const __half*>(p)[i]);
+    else
+        return static_cast<const float*>(p)[i];
+}
+
+// channel LLR -> fixed-point grid (integer-valued float).  Mirrors ingest() of the oracle.
+__device__ __forceinline__ float ingest(float x, float scale, bool core) {
+    float y = x * scale;
+    y = (y != y) ? 0.0f : y;
+    y = fminf(fmaxf(y, -127.0f), 127.0f);
+    y = rintf(y) + 0.0f; // +0.0f canonicalises -0
+    if (core && fabsf(x) == __builtin_inff()) y = copysignf(1048576.0f, x);
+    return y;
+}
+
+template <int BG> struct DecState {
+    uint32_t rm[BGD<BG>::NW];  // check-to-variable messages, int8 x4
+    uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4
+};
+
+// One base-graph layer for this thread's check row.  zrot = z * sbw (ring position in bytes, without the
+// codeword slot), cwoff = codeword slot bytes, rot[e] = P_e * sbw.
+template <int BG, int L, bool MULTI>
+__device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zrot, uint32_t cwoff, const DecArgs& a,
+                                      ctab_t rot, uint32_t& esign_lo, uint32_t& esign_hi, float* app_ext) {
+    using G = BGD<BG>;
+    constexpr int e0 = G::row_ptr(L);
+    constexpr int deg = G::row_ptr(L + 1) - e0;
+    constexpr bool HAS_EXT = (L >= 4);
+    constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
+    constexpr int ce0 = G::core_base(L);
+    const uint32_t zsb = (uint32_t)a.Z * (uint32_t)a.sbw;
+
+    float t[ncore];
+    uint32_t ad[ncore];
+    float m1 = __builtin_inff(), m2 = __builtin_inff();
+    uint32_t S = 0;
+    static_for<ncore>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int c = G::col(e0 + j);
+        constexpr int ce = ce0 + j;
+        const uint32_t w1 = zrot + (uint32_t)rot[e0 + j];
+        const uint32_t w2 = w1 - zsb; // wraps to a huge value unless w1 >= Z*sbw
+        uint32_t wa = min(w1, w2);
+        if constexpr (MULTI) wa += cwoff;
+        ad[j] = wa;
+        const float app = *reinterpret_cast<const float*>(lds + wa + 4 * c);
+        const float r = byte_to_f32<ce & 3>(st.rm[ce >> 2]);
+        const float tj = app - r;
+        t[j] = tj;
+        const float aj = fabsf(tj);
+        m2 = __builtin_amdgcn_fmed3f(aj, m1, m2);
+        m1 = fminf(m1, aj);
+        S ^= fbits(tj);
+    });
+    float lam = 0.0f;
+    if constexpr (HAS_EXT) {
+        lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
+        const float al = fabsf(lam);
+        m2 = __builtin_amdgcn_fmed3f(al, m1, m2);
+        m1 = fminf(m1, al);
+        S ^= fbits(lam);
+    }
+    const float M1 = fminf(rintf(a.alpha * m1), 127.0f);
+    const float M2 = fminf(rintf(a.alpha * m2), 127.0f);
+    static_for<ncore>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int c = G::col(e0 + j);
+        constexpr int ce = ce0 + j;
+        const float tj = t[j];
+        const float mag = (fabsf(tj) == m1) ? M2 : M1;
+        const float r = __uint_as_float(fbits(mag) | ((S ^ fbits(tj)) & 0x80000000u));
+        f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
+        *reinterpret_cast<float*>(lds + ad[j] + 4 * c) = tj + r;
+    });
+    if constexpr (HAS_EXT) {
+        if (a.need_ext) { // early termination and/or soft output: a-posteriori value of the extension bit
+            const float mag = (fabsf(lam) == m1) ? M2 : M1;
+            const float r = __uint_as_float(fbits(mag) | ((S ^ fbits(lam)) & 0x80000000u));
+            const float ae = lam + r;
+            // esign is cleared at the start of every iteration, so a plain OR rebuilds bit L-4
+            if constexpr (L - 4 < 32) esign_lo |= (fbits(ae) >> 31) << (L - 4);
+            else esign_hi |= (fbits(ae) >> 31) << (L - 36);
+            if (app_ext) { // soft output is a test/debug path: keep its address arithmetic out of the hot loop
+                float* p = app_ext;
+                asm volatile("" : "+v"(p));
+                p[(size_t)(G::NC + L - 4) * launder(a.Z)] = ae * a.inv_scale;
+            }
+        }
+    }
+}
+
+// parity of check row (L, z) on the iteration-end snapshot
+template <int BG, int L, bool MULTI>
+__device__ __forceinline__ uint32_t row_parity(char* lds, uint32_t zrot, uint32_t cwoff, const DecArgs& a,
+                                               ctab_t rot, uint32_t esign_lo, uint32_t esign_hi) {
+    using G = BGD<BG>;
+    constexpr int e0 = G::row_ptr(L);
+    constexpr int deg = G::row_ptr(L + 1) - e0;
+    constexpr bool HAS_EXT = (L >= 4);
+    constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
+    const uint32_t zsb = (uint32_t)a.Z * (uint32_t)a.sbw;
+    uint32_t p = 0;
+    static_for<ncore>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int c = G::col(e0 + j);
+        const uint32_t w1 = zrot + (uint32_t)rot[e0 + j];
+        const uint32_t w2 = w1 - zsb;
+        uint32_t ra = min(w1, w2);
+        if constexpr (MULTI) ra += cwoff;
+        p ^= fbits(*reinterpret_cast<const float*>(lds + ra + 4 * c));
+    });
+    p >>= 31;
+    if constexpr (HAS_EXT) p ^= (L - 4 < 32 ? esign_lo >> ((L - 4) & 31) : esign_hi >> ((L - 36) & 31)) & 1u;
+    return p;
+}
+
+template <int BG, bool MULTI, int DT>
+__global__ __launch_bounds__(512) void nrldpc_decode_kernel(const DecArgs a, const int32_t* __restrict__ rot_tab) {
+    using G = BGD<BG>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int Z = a.Z;
+    int cwl = 0, z = tid;
+    if constexpr (MULTI) { cwl = tid / Z; z = tid - cwl * Z; }
+    const int cw = blockIdx.x * a.ncw + cwl;
+    const bool active = (cwl < a.ncw) && (cw < a.batch) && (z < Z);
+    const uint32_t cwoff = (uint32_t)cwl * (uint32_t)(G::NCP * 4);
+    const uint32_t zrot = (uint32_t)z * (uint32_t)a.sbw;
+    const uint32_t zb = zrot + cwoff;
+    int* flags = reinterpret_cast<int*>(lds + (size_t)Z * a.sbw);
+    const size_t ncwz = (size_t)G::COLS * Z;
+
+    DecState<BG> st;
+#pragma unroll
+    for (int i = 0; i < G::NW; ++i) st.rm[i] = 0;
+#pragma unroll
+    for (int i = 0; i < G::NXW; ++i) st.xq[i] = 0;
+    uint32_t esign_lo = 0, esign_hi = 0;
+    float* app_row = nullptr; // &app[cw][z]
+
+    if (active) {
+        const size_t base = (size_t)cw * ncwz;
+        if (a.app) app_row = a.app + base + z;
+        // Issue every global load of a group before the first use so the HBM round trips overlap.
+        {   // core columns -> LDS, ring position z
+            float x[G::NC];
+            static_for<G::NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                x[c] = load_llr<DT>(a.llr, base + (size_t)c * Z + z);
+            });
+            static_for<G::NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                *reinterpret_cast<float*>(lds + zb + 4 * c) = ingest(x[c], a.scale, true);
+            });
+        }
+        {   // extension columns -> int8 registers (thread-private: shift 0, degree 1)
+            float x[G::NEXT];
+            static_for<G::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                x[i] = load_llr<DT>(a.llr, base + (size_t)(G::NC + i) * Z + z);
+            });
+            static_for<G::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                f32_to_byte<i & 3>(st.xq[i >> 2], ingest(x[i], a.scale, false));
+            });
+        }
+        if (app_row) { // soft output of columns whose layer is inactive = the ingested channel value
+            static_for<G::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                app_row[(size_t)(G::NC + i) * Z] = byte_to_f32<i & 3>(st.xq[i >> 2]) * a.inv_scale;
+            });
+        }
+    }
+    __syncthreads();
+
+    bool done = !active;
+    int my_iters = a.max_iter;
+    for (int it = 1; it <= a.max_iter; ++it) {
+        const ctab_t rot = launder(as_ctab(rot_tab));
+        if (!done) { esign_lo = 0; esign_hi = 0; }
+        static_for<G::ROWS>([&](auto lc) {
+            constexpr int L = decltype(lc)::value;
+            if (L < launder(a.n_layers)) {
+                if (!done) layer<BG, L, MULTI>(st, lds, zrot, cwoff, a, rot, esign_lo, esign_hi, app_row);
+                __syncthreads();
+            }
+        });
+        if (a.early_term) {
+            if (tid <= a.ncw) flags[tid] = 0; // flags[ncw] = "some codeword of this workgroup still fails"
+            __syncthreads();
+            if (!done) {
+                uint32_t bad = 0;
+                static_for<G::ROWS>([&](auto lc) {
+                    constexpr int L = decltype(lc)::value;
+                    if (L < launder(a.n_layers)) bad |= row_parity<BG, L, MULTI>(lds, zrot, cwoff, a, rot, esign_lo, esign_hi);
+                });
+                if (bad) { flags[cwl] = 1; flags[a.ncw] = 1; }
+            }
+            __syncthreads();
+            if (!done && flags[cwl] == 0) { done = true; my_iters = it; }
+            if (flags[a.ncw] == 0) break;
+        }
+    }
+
+    if (active) {
+        if (a.iters && z == 0) a.iters[cw] = my_iters;
+        uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * Z);
+        static_for<G::NC>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const float val = *reinterpret_cast<const float*>(lds + zb + 4 * c);
+            if (c < G::KB) hard[(size_t)c * Z + z] = val < 0.0f ? 1 : 0;
+            if (app_row) app_row[(size_t)c * Z] = val * a.inv_scale;
+        });
+    }
+}
+
+template <int BG, bool MULTI, int DT> static hipError_t launch_t(const DecArgs& a, int grid, int threads, size_t lds, hipStream_t s) {
+    auto k = nrldpc_decode_kernel<BG, MULTI, DT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a, a.rot);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
+    const int grid = (a.batch + a.ncw - 1) / a.ncw;
+    const bool multi = a.ncw > 1;
+    const bool f16 = a.llr_kind == NRLDPC_K_F16;
+#define NRLDPC_DISPATCH(B, M)                                                                      \
+    return f16 ? launch_t<B, M, NRLDPC_K_F16>(a, grid, threads, lds_bytes, stream)                 \
+               : launch_t<B, M, NRLDPC_K_F32>(a, grid, threads, lds_bytes, stream)
+    if (bg == 1) {
+        if (multi) { NRLDPC_DISPATCH(1, true); } else { NRLDPC_DISPATCH(1, false); }
+    } else {
+        if (multi) { NRLDPC_DISPATCH(2, true); } else { NRLDPC_DISPATCH(2, false); }
+    }
+#undef NRLDPC_DISPATCH
+}
+
+} // namespace nrldpc

@@ -1,0 +1,105 @@
+// nrldpc_sched.h -- host-side construction of the decoder's per-(BG, Z, n_layers) layer schedule.
+//
+// The reference materialises a sparse H with get_pcm.m:1-11 from get_3gpp_base_graph.m's table
+// (NRLDPC.m:433-440).  The MI355X decoder never builds H; it needs, per base-graph edge, only
+// rotation amounts.  Check (l, z) touches variable (c, (z + P_lc) mod Z)  (get_pcm.m:8).
+//
+// LDS convention: the a-posteriori block of core column c sits at ring positions 0..Z-1 in natural
+// order; check row z reads AND writes ring position (z + P_e) mod Z for edge e.  Within one layer
+// every LDS word is therefore touched by exactly one thread (no intra-layer hazard, one barrier per
+// layer).  A "write-rotated" variant that reads at position z and writes at (z + D_e) mod Z saves
+// the live address registers but lets one wave's pass-2 write race another wave's pass-1 read of the
+// same layer, so it is not used.
+#ifndef NRLDPC_SCHED_H
+#define NRLDPC_SCHED_H
+
+#include <cstdint>
+#include <vector>
+
+#include "nr_bg_tables.h"
+
+namespace nrldpc {
+
+struct BaseGraph {
+    int bg, nrows, ncols, kb, nnz;
+    const uint16_t* row_ptr;
+    const uint8_t* col;
+    const uint16_t (*shift)[NR_BG1_NNZ];  // only valid for bg == 1
+    const uint16_t (*shift2)[NR_BG2_NNZ]; // only valid for bg == 2
+    int raw_shift(int ils, int e) const { return bg == 1 ? shift[ils][e] : shift2[ils][e]; }
+};
+
+inline bool base_graph(int bg, BaseGraph* g) {
+    if (bg == 1) {
+        *g = BaseGraph{1, NR_BG1_ROWS, NR_BG1_COLS, 22, NR_BG1_NNZ, nr_bg1_row_ptr, nr_bg1_col, nr_bg1_shift, nullptr};
+        return true;
+    }
+    if (bg == 2) {
+        *g = BaseGraph{2, NR_BG2_ROWS, NR_BG2_COLS, 10, NR_BG2_NNZ, nr_bg2_row_ptr, nr_bg2_col, nullptr, nr_bg2_shift};
+        return true;
+    }
+    return false;
+}
+
+// get_3gpp_set_index.m:5-11
+inline int set_index(int Z) {
+    for (int s = 0; s < 8; ++s)
+        for (int k = 0; k < 9 && nr_lifting_sets[s][k]; ++k)
+            if (nr_lifting_sets[s][k] == Z) return s;
+    return -1;
+}
+
+// get_3gpp_lifting_size.m:5-16
+inline int lifting_size(int K_b, int K_prime) {
+    int best = -1;
+    for (int s = 0; s < 8; ++s)
+        for (int k = 0; k < 9 && nr_lifting_sets[s][k]; ++k) {
+            int z = nr_lifting_sets[s][k];
+            if (K_b * z >= K_prime && (best < 0 || z < best)) best = z;
+        }
+    return best;
+}
+
+struct Schedule {
+    BaseGraph g;
+    int Z = 0, ils = 0, n_layers = 0;
+    int nc = 0;      // core columns kb+4 (kept in LDS)
+    int ncp = 0;     // padded (odd) dword stride between ring positions
+    int ncw = 1;     // codewords per workgroup
+    int threads = 0; // workgroup size
+    int sbw = 0;     // bytes between consecutive ring positions = ncw*ncp*4
+    size_t lds_bytes = 0;
+    // per base-graph edge (indexed by table edge id; extension-parity edges hold 0):
+    std::vector<int32_t> shift;  // P_e = table shift mod Z
+    std::vector<int32_t> rot;    // P_e * sbw  (ring rotation in bytes)
+};
+
+// Returns false for an unsupported (bg, Z, n_layers).
+inline bool build_schedule(int bg, int Z, int n_layers, Schedule* s) {
+    if (!base_graph(bg, &s->g)) return false;
+    const BaseGraph& g = s->g;
+    s->ils = set_index(Z);
+    if (s->ils < 0) return false;
+    if (n_layers == 0) n_layers = g.nrows;
+    if (n_layers < 4 || n_layers > g.nrows) return false;
+    s->Z = Z;
+    s->n_layers = n_layers;
+    s->nc = g.kb + 4;
+    s->ncp = s->nc | 1;
+    int ncw = 512 / Z;
+    if (ncw < 1) ncw = 1;
+    s->ncw = ncw;
+    s->threads = ((ncw * Z + 63) / 64) * 64;
+    s->sbw = ncw * s->ncp * 4;
+    s->lds_bytes = (((size_t)Z * s->sbw + 4 * (size_t)(ncw + 1)) + 15) / 16 * 16; // + early-termination flags
+    s->shift.assign(g.nnz, 0);
+    s->rot.assign(g.nnz, 0);
+    for (int e = 0; e < g.nnz; ++e) {
+        s->shift[e] = g.raw_shift(s->ils, e) % Z;
+        s->rot[e] = (g.col[e] < s->nc) ? s->shift[e] * s->sbw : 0;
+    }
+    return true;
+}
+
+} // namespace nrldpc
+#endif

@@ -1,0 +1,97 @@
+"""ctypes binding of the CPU oracle (oracle/nrldpc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BG_DIMS = {1: (46, 68, 22), 2: (42, 52, 10)}  # rows, cols, kb
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libnrldpc_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        i32, f32 = C.c_int, C.c_float
+        P = C.c_void_p
+        L.orc_set_index.argtypes = [i32]
+        L.orc_lifting_size.argtypes = [i32, i32]
+        L.orc_graph_edges.argtypes = [i32, i32, P, P, P]
+        L.orc_syndrome_weight.argtypes = [i32, i32, i32, P]
+        L.orc_encode.argtypes = [i32, i32, P, i32, P]
+        L.orc_decode_nmsq.argtypes = [i32, i32, i32, i32, i32, f32, i32, P, i32, P, P, P]
+        L.orc_decode_bp_flood.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32]
+        L.orc_set_threads.argtypes = [i32]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def set_index(Z):
+    return lib().orc_set_index(Z)
+
+
+def lifting_size(kb, kprime):
+    return lib().orc_lifting_size(kb, kprime)
+
+
+def graph_edges(bg, Z):
+    nnz = 316 if bg == 1 else 197
+    r = np.zeros(nnz, np.int32); c = np.zeros(nnz, np.int32); s = np.zeros(nnz, np.int32)
+    n = lib().orc_graph_edges(bg, Z, _p(r), _p(c), _p(s))
+    assert n == nnz
+    return r, c, s
+
+
+def syndrome_weight(bg, Z, cw, n_layers=0):
+    cw = np.ascontiguousarray(cw, np.uint8)
+    return lib().orc_syndrome_weight(bg, Z, n_layers, _p(cw))
+
+
+def encode(bg, Z, info):
+    rows, cols, kb = BG_DIMS[bg]
+    info = np.ascontiguousarray(info, np.uint8).reshape(-1, kb * Z)
+    cw = np.zeros((info.shape[0], cols * Z), np.uint8)
+    rc = lib().orc_encode(bg, Z, _p(info), info.shape[0], _p(cw))
+    assert rc == 0, rc
+    return cw
+
+
+def decode_nmsq(bg, Z, llr, max_iter, n_layers=0, early_term=False, alpha=0.75, scale=8, want_app=False):
+    rows, cols, kb = BG_DIMS[bg]
+    llr = np.ascontiguousarray(llr, np.float64).reshape(-1, cols * Z)
+    B = llr.shape[0]
+    hard = np.zeros((B, kb * Z), np.uint8)
+    iters = np.zeros(B, np.int32)
+    app = np.zeros((B, cols * Z), np.float32) if want_app else None
+    rc = lib().orc_decode_nmsq(bg, Z, n_layers, max_iter, int(early_term), alpha, scale, _p(llr), B,
+                               _p(hard), _p(iters), _p(app))
+    assert rc == 0, rc
+    return (hard, iters, app) if want_app else (hard, iters)
+
+
+def decode_bp_flood(bg, Z, llr, max_iter, n_layers=0, nthreads=0):
+    rows, cols, kb = BG_DIMS[bg]
+    llr = np.ascontiguousarray(llr, np.float64).reshape(-1, cols * Z)
+    B = llr.shape[0]
+    hard = np.zeros((B, kb * Z), np.uint8)
+    iters = np.zeros(B, np.int32)
+    rc = lib().orc_decode_bp_flood(bg, Z, n_layers, max_iter, _p(llr), B, _p(hard), _p(iters), nthreads)
+    assert rc == 0, rc
+    return hard, iters
