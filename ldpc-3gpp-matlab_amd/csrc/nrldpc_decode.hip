@@ -126,11 +126,12 @@ template <int BG> struct DecState {
     uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4
 };
 
-// One base-graph layer for this thread's check row.  zrot = z * sbw (ring position in bytes, without the
-// codeword slot), cwoff = codeword slot bytes, rot[e] = P_e * sbw.
-template <int BG, int L, bool MULTI>
-__device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zrot, uint32_t cwoff, const DecArgs& a,
-                                      ctab_t rot, uint32_t& esign_lo, uint32_t& esign_hi, float* app_ext) {
+// One base-graph layer for this thread's check row.  With ncw codewords per workgroup the LDS ring of a
+// column has ncw*Z slots, slot u = z*ncw + cwl; rotating z by P is rotating u by P*ncw, so the same
+// unsigned-min wrap works on zb = u * (NCP*4) with rot[e] = P_e * sbw and ring size Z*sbw bytes.
+template <int BG, int L>
+__device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zb, const DecArgs& a, ctab_t rot,
+                                      uint32_t& esign_lo, uint32_t& esign_hi, float* app_ext) {
     using G = BGD<BG>;
     constexpr int e0 = G::row_ptr(L);
     constexpr int deg = G::row_ptr(L + 1) - e0;
@@ -147,10 +148,9 @@ __device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zrot
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);
         constexpr int ce = ce0 + j;
-        const uint32_t w1 = zrot + (uint32_t)rot[e0 + j];
+        const uint32_t w1 = zb + (uint32_t)rot[e0 + j];
         const uint32_t w2 = w1 - zsb; // wraps to a huge value unless w1 >= Z*sbw
-        uint32_t wa = min(w1, w2);
-        if constexpr (MULTI) wa += cwoff;
+        const uint32_t wa = min(w1, w2);
         ad[j] = wa;
         const float app = *reinterpret_cast<const float*>(lds + wa + 4 * c);
         const float r = byte_to_f32<ce & 3>(st.rm[ce >> 2]);
@@ -199,9 +199,9 @@ __device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zrot
 }
 
 // parity of check row (L, z) on the iteration-end snapshot
-template <int BG, int L, bool MULTI>
-__device__ __forceinline__ uint32_t row_parity(char* lds, uint32_t zrot, uint32_t cwoff, const DecArgs& a,
-                                               ctab_t rot, uint32_t esign_lo, uint32_t esign_hi) {
+template <int BG, int L>
+__device__ __forceinline__ uint32_t row_parity(char* lds, uint32_t zb, const DecArgs& a, ctab_t rot, uint32_t esign_lo,
+                                               uint32_t esign_hi) {
     using G = BGD<BG>;
     constexpr int e0 = G::row_ptr(L);
     constexpr int deg = G::row_ptr(L + 1) - e0;
@@ -212,10 +212,9 @@ __device__ __forceinline__ uint32_t row_parity(char* lds, uint32_t zrot, uint32_
     static_for<ncore>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);
-        const uint32_t w1 = zrot + (uint32_t)rot[e0 + j];
+        const uint32_t w1 = zb + (uint32_t)rot[e0 + j];
         const uint32_t w2 = w1 - zsb;
-        uint32_t ra = min(w1, w2);
-        if constexpr (MULTI) ra += cwoff;
+        const uint32_t ra = min(w1, w2);
         p ^= fbits(*reinterpret_cast<const float*>(lds + ra + 4 * c));
     });
     p >>= 31;
@@ -223,19 +222,16 @@ __device__ __forceinline__ uint32_t row_parity(char* lds, uint32_t zrot, uint32_
     return p;
 }
 
-template <int BG, bool MULTI, int DT>
-__global__ __launch_bounds__(512) void nrldpc_decode_kernel(const DecArgs a, const int32_t* __restrict__ rot_tab) {
+template <int BG, int DT>
+__global__ __launch_bounds__(768) void nrldpc_decode_kernel(const DecArgs a, const int32_t* __restrict__ rot_tab) {
     using G = BGD<BG>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int Z = a.Z;
-    int cwl = 0, z = tid;
-    if constexpr (MULTI) { cwl = tid / Z; z = tid - cwl * Z; }
+    const int cwl = tid / Z, z = tid - cwl * Z;
     const int cw = blockIdx.x * a.ncw + cwl;
     const bool active = (cwl < a.ncw) && (cw < a.batch) && (z < Z);
-    const uint32_t cwoff = (uint32_t)cwl * (uint32_t)(G::NCP * 4);
-    const uint32_t zrot = (uint32_t)z * (uint32_t)a.sbw;
-    const uint32_t zb = zrot + cwoff;
+    const uint32_t zb = (uint32_t)z * (uint32_t)a.sbw + (uint32_t)cwl * (uint32_t)(G::NCP * 4);
     int* flags = reinterpret_cast<int*>(lds + (size_t)Z * a.sbw);
     const size_t ncwz = (size_t)G::COLS * Z;
 
@@ -290,7 +286,7 @@ __global__ __launch_bounds__(512) void nrldpc_decode_kernel(const DecArgs a, con
         static_for<G::ROWS>([&](auto lc) {
             constexpr int L = decltype(lc)::value;
             if (L < launder(a.n_layers)) {
-                if (!done) layer<BG, L, MULTI>(st, lds, zrot, cwoff, a, rot, esign_lo, esign_hi, app_row);
+                if (!done) layer<BG, L>(st, lds, zb, a, rot, esign_lo, esign_hi, app_row);
                 __syncthreads();
             }
         });
@@ -301,7 +297,7 @@ __global__ __launch_bounds__(512) void nrldpc_decode_kernel(const DecArgs a, con
                 uint32_t bad = 0;
                 static_for<G::ROWS>([&](auto lc) {
                     constexpr int L = decltype(lc)::value;
-                    if (L < launder(a.n_layers)) bad |= row_parity<BG, L, MULTI>(lds, zrot, cwoff, a, rot, esign_lo, esign_hi);
+                    if (L < launder(a.n_layers)) bad |= row_parity<BG, L>(lds, zb, a, rot, esign_lo, esign_hi);
                 });
                 if (bad) { flags[cwl] = 1; flags[a.ncw] = 1; }
             }
@@ -323,8 +319,8 @@ __global__ __launch_bounds__(512) void nrldpc_decode_kernel(const DecArgs a, con
     }
 }
 
-template <int BG, bool MULTI, int DT> static hipError_t launch_t(const DecArgs& a, int grid, int threads, size_t lds, hipStream_t s) {
-    auto k = nrldpc_decode_kernel<BG, MULTI, DT>;
+template <int BG, int DT> static hipError_t launch_t(const DecArgs& a, int grid, int threads, size_t lds, hipStream_t s) {
+    auto k = nrldpc_decode_kernel<BG, DT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -335,17 +331,12 @@ template <int BG, bool MULTI, int DT> static hipError_t launch_t(const DecArgs& 
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
     const int grid = (a.batch + a.ncw - 1) / a.ncw;
-    const bool multi = a.ncw > 1;
     const bool f16 = a.llr_kind == NRLDPC_K_F16;
-#define NRLDPC_DISPATCH(B, M)                                                                      \
-    return f16 ? launch_t<B, M, NRLDPC_K_F16>(a, grid, threads, lds_bytes, stream)                 \
-               : launch_t<B, M, NRLDPC_K_F32>(a, grid, threads, lds_bytes, stream)
-    if (bg == 1) {
-        if (multi) { NRLDPC_DISPATCH(1, true); } else { NRLDPC_DISPATCH(1, false); }
-    } else {
-        if (multi) { NRLDPC_DISPATCH(2, true); } else { NRLDPC_DISPATCH(2, false); }
-    }
-#undef NRLDPC_DISPATCH
+    if (bg == 1)
+        return f16 ? launch_t<1, NRLDPC_K_F16>(a, grid, threads, lds_bytes, stream)
+                   : launch_t<1, NRLDPC_K_F32>(a, grid, threads, lds_bytes, stream);
+    return f16 ? launch_t<2, NRLDPC_K_F16>(a, grid, threads, lds_bytes, stream)
+               : launch_t<2, NRLDPC_K_F32>(a, grid, threads, lds_bytes, stream);
 }
 
 } // namespace nrldpc

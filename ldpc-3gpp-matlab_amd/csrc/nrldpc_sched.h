@@ -86,7 +86,7 @@ inline bool build_schedule(int bg, int Z, int n_layers, Schedule* s) {
     s->n_layers = n_layers;
     s->nc = g.kb + 4;
     s->ncp = s->nc | 1;
-    int ncw = 512 / Z;
+    int ncw = 768 / Z; // 12 wave64 per workgroup at Z = 384: three per SIMD, evenly
     if (ncw < 1) ncw = 1;
     s->ncw = ncw;
     s->threads = ((ncw * Z + 63) / 64) * 64;
