@@ -48,11 +48,22 @@ def lib_path():
     return _build.LIB
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7; if this
+    library pulled in /opt/rocm's copy first, torch would later find "No HIP GPUs".  Importing torch
+    first (when it is installed) makes both use the same runtime; without torch nothing happens."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load():
     """Load (building first if needed) libnrldpc_hip.so.  Raises if it cannot be produced."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     path = _build.LIB
     if not os.path.exists(path):
         path = _build.build_lib()

@@ -1,0 +1,169 @@
+"""NRLDPCDecoder: host-side mirror of the reference's decoder System object (NRLDPCDecoder.m).
+
+Same properties (I_HARQ Nontunable, iterations), same step()/reset() protocol, same HARQ state
+(d_tilde_buffer, b_hat_buffer, code_block_CRC_passed; NRLDPCDecoder.m:64-95, 343-356) and the same
+output convention: A decoded bits, or an empty array when a CRC fails (:336-339).
+
+Stage 4 (LDPC_coding, :245-268) is the hot path: all C code blocks of the transport block go to the
+GPU as one batch through nrldpc_decode (the reference decodes them one by one, :257).  The decoding
+algorithm is the build's layered normalised min-sum, not comm.LDPCDecoder's flooding sum-product
+(see DESIGN.md); `iterations` keeps the reference's meaning of 'MaximumIterationCount' and the
+parity-check early stop of :120 stays on.
+"""
+import numpy as np
+
+from . import chain
+from ._capi import Codec, NRLDPCError
+from .nrldpc import NRLDPC
+
+
+def default_alpha(bg, n_layers):
+    """Min-sum normalisation by code rate (the reference defines none; tuned on BLER vs its
+    sum-product semantics): low-rate graphs with many degree-1 extension rows want a
+    smaller factor."""
+    frac = n_layers / (46.0 if bg == 1 else 42.0)
+    if frac > 0.6:
+        return 0.625
+    if frac > 0.3:
+        return 0.6875
+    return 0.75
+
+
+class NRLDPCDecoder(NRLDPC):
+    _NONTUNABLE = NRLDPC._NONTUNABLE + ("I_HARQ",)
+    _TUNABLE = NRLDPC._TUNABLE + ("iterations",)
+
+    def __init__(self, device_id=0, alpha=None, llr_scale=0, prune_layers=True, **kw):
+        self._I_HARQ = 0        # NRLDPCDecoder.m:34
+        self._iterations = 50   # NRLDPCDecoder.m:41
+        super().__init__(**kw)
+        self._device_id, self._alpha, self._llr_scale = device_id, alpha, llr_scale
+        self._prune = prune_layers
+        self._codec = None
+        self._codec_layers = None
+        self.d_tilde_buffer = None
+        self.b_hat_buffer = None
+        self.code_block_CRC_passed = None
+        self._layers_seen = 4
+        self.last_iterations = None
+
+    I_HARQ = property(lambda s: s._I_HARQ)
+
+    @I_HARQ.setter
+    def I_HARQ(self, v):
+        self._set_nontunable("I_HARQ", int(v))
+
+    iterations = property(lambda s: s._iterations)
+
+    @iterations.setter
+    def iterations(self, v):
+        # read at setup only, as in the reference (NRLDPCDecoder.m:120)
+        self._iterations = int(v)
+
+    # -- System-object protocol ------------------------------------------------------------------
+    def _make_codec(self, n_layers):
+        if self._codec is not None:
+            self._codec.close()
+        alpha = self._alpha if self._alpha is not None else default_alpha(self.BG, n_layers)
+        self._codec = Codec(self.BG, self.Z_c, max_iter=self._setup_iterations, n_layers=n_layers,
+                            early_term=True, alpha=alpha, llr_scale=self._llr_scale,
+                            llr_dtype=np.float32, device_id=self._device_id)
+        self._codec_layers = n_layers
+
+    def _setup(self):  # NRLDPCDecoder.m:107-130
+        self.validate()
+        self._setup_iterations = self._iterations
+        object.__setattr__(self, "_locked", True)
+        self.reset()
+
+    def reset(self):  # NRLDPCDecoder.m:343-356
+        if not self._locked:
+            return
+        self.d_tilde_buffer = np.zeros((self.C, self.N_cb), np.float64)
+        self.b_hat_buffer = np.zeros(self.B, np.uint8)
+        self.code_block_CRC_passed = np.zeros(self.C, np.uint8)
+        self._layers_seen = 4
+
+    def release(self):
+        if self._codec is not None:
+            self._codec.close()
+            self._codec = None
+        super().release()
+
+    def __call__(self, g_tilde):
+        return self.step(g_tilde)
+
+    def step(self, g_tilde):
+        """g_tilde: G LLRs (positive = bit 0) -> a_hat: A bits, or an empty array on CRC failure."""
+        if not self._locked:
+            self._setup()
+        else:
+            self.validate()
+        g_tilde = np.asarray(g_tilde, np.float64)
+        if g_tilde.ndim == 2 and g_tilde.shape[1] == 1:
+            g_tilde = g_tilde[:, 0]
+        if g_tilde.ndim != 1 or g_tilde.size != self.G:
+            raise NRLDPCError("g_tilde should be a column vector of length G.")
+        d_tilde = self.rate_recover(g_tilde)
+        c_hat = self.LDPC_coding(d_tilde)
+        b_hat = self.code_block_segmentation(c_hat)
+        return self.crc_calculation(b_hat)
+
+    # -- stages ----------------------------------------------------------------------------------
+    def rate_recover(self, g_tilde):
+        """Stages 1-3: de-concatenate, de-interleave, soft-combining bit de-selection and the HARQ
+        buffer (NRLDPCDecoder.m:143-242).  Filler positions are marked NaN as in the reference."""
+        N_, Z, K_, Kp, N_cb = self.N, self.Z_c, self.K, int(self.K_prime), self.N_cb
+        d = np.zeros((self.C, N_), np.float64)
+        for r, (off, dpos, fpos) in enumerate(chain.g_to_d_maps(self)):
+            if dpos.size:
+                np.add.at(d[r], dpos, g_tilde[off + fpos])  # repetition soft-combines (:229-231)
+        if self.I_HARQ != 0:  # :236-239
+            d[:, :N_cb] += self.d_tilde_buffer
+            self.d_tilde_buffer = d[:, :N_cb].copy()
+        d[:, max(Kp - 2 * Z, 0): K_ - 2 * Z] = np.nan  # :224
+        return d
+
+    def LDPC_coding(self, d_tilde):  # NRLDPCDecoder.m:245-268
+        Z, K_ = self.Z_c, self.K
+        cw = np.concatenate([np.zeros((self.C, 2 * Z)), d_tilde], axis=1)  # :262
+        filler = np.isnan(cw[0, :K_])
+        cw[np.isnan(cw)] = np.inf  # :264
+        n_layers = 0
+        if self._prune:
+            self._layers_seen = max(self._layers_seen, self.active_layers()) if self.I_HARQ else self.active_layers()
+            n_layers = self._layers_seen
+        want = n_layers if n_layers else (46 if self.BG == 1 else 42)
+        if self._codec is None or self._codec_layers != want:
+            self._make_codec(want)
+        hard, iters = self._codec.decode(cw.astype(np.float32), want_iters=True)  # :265
+        self.last_iterations = iters
+        c_hat = hard.astype(np.float64)
+        c_hat[:, filler] = np.nan  # :266
+        return c_hat
+
+    def code_block_segmentation(self, c_hat):  # NRLDPCDecoder.m:271-318
+        C_, Kp, L = self.C, int(self.K_prime), self.code_block_L
+        flags = self.CBGTI_flags
+        b_hat = self.b_hat_buffer.copy() if self.I_HARQ != 0 else np.zeros(self.B, np.uint8)
+        passed = self.code_block_CRC_passed.copy()
+        s = 0
+        for r in range(C_):
+            blk = c_hat[r, :Kp].astype(np.uint8)
+            failed = False
+            if C_ > 1:  # CB-CRC only when segmented (:298-301)
+                failed = bool(chain.crc_bits(blk, self.code_block_CRC_polynomial, L).any())
+            if not failed and flags[r] == 1:
+                b_hat[s: s + Kp - L] = blk[: Kp - L]
+                passed[r] = 1
+            s += Kp - L
+        if self.I_HARQ != 0:
+            self.b_hat_buffer = b_hat.copy()
+        self.code_block_CRC_passed = passed
+        return b_hat
+
+    def crc_calculation(self, b_hat):  # NRLDPCDecoder.m:321-340
+        failed = bool(chain.crc_bits(b_hat, self.transport_block_CRC_polynomial, self.transport_block_L).any())
+        if failed or (self.code_block_CRC_passed == 0).any():
+            return np.zeros(0, np.uint8)
+        return b_hat[: self.A].copy()

@@ -1,0 +1,66 @@
+"""The C-ABI shared object loads and exports every function include/nrldpc.h declares.
+No compute calls here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "nrldpc.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nrldpc_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_lists_the_boundary():
+    names = declared_functions()
+    for must in ("nrldpc_create", "nrldpc_decode", "nrldpc_decode_dev", "nrldpc_encode", "nrldpc_destroy",
+                 "nrldpc_strerror"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert set(pkg._capi.EXPORTS) <= set(declared_functions())
+    assert b"gfx950" in lib.nrldpc_version()
+
+
+def test_no_torch_types_in_signatures():
+    txt = open(os.path.join(ROOT, "include", "nrldpc.h")).read()
+    assert "torch" not in txt and "at::" not in txt and "hipStream_t stream" not in txt
+
+
+def test_helpers_without_device(pkg):
+    lib = pkg.load()
+    assert lib.nrldpc_set_index(384) == 1 and lib.nrldpc_set_index(17) == -1
+    assert lib.nrldpc_lifting_size(22, 8448) == 384
+    assert lib.nrldpc_strerror(1) == b"unsupported parameters"
+
+
+def test_create_rejects_bad_parameters_before_touching_the_device(pkg):
+    C = pkg._capi
+    lib = pkg.load()
+    h = ctypes.c_void_p()
+    for bg, Z, nl, it in ((3, 384, 0, 10), (1, 17, 0, 10), (1, 384, 0, 0), (1, 384, 0, 5000)):
+        cfg = C.Cfg(bg, Z, nl, it, 1, 0.0, 0, 0, 0, 0)
+        assert lib.nrldpc_create(ctypes.byref(cfg), ctypes.byref(h)) == C.ERR_UNSUPPORTED
+        assert h.value is None
+    cfg = C.Cfg(1, 384, 3, 10, 1, 0.0, 0, 0, 0, 0)  # fewer than the 4 core layers
+    assert lib.nrldpc_create(ctypes.byref(cfg), ctypes.byref(h)) == C.ERR_UNSUPPORTED
+    with pytest.raises(pkg.UnsupportedParameters):
+        pkg.Codec(1, 100)
+
+
+def test_product_never_imports_the_oracle():
+    """Guard for the rule that only tests/, smoke() and bench's cpu_baseline may touch oracle/."""
+    pk = os.path.join(ROOT, "ldpc-3gpp-matlab_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "oracle/" not in src.replace("oracle/nrldpc_oracle.c", ""), f

@@ -1,0 +1,72 @@
+"""Host-side TS 38.212 stages around the core (no GPU): CRC known answers and the rate-matching
+index maps checked against literal restatements of the reference's per-element loops."""
+import numpy as np
+import pytest
+
+
+def test_crc_check_values(pkg):
+    msg = np.unpackbits(np.frombuffer(b"123456789", np.uint8))
+    val = lambda bits: int("".join(map(str, bits)), 2)
+    assert val(pkg.chain.crc_bits(msg, 0x11021, 16)) == 0x31C3      # CRC-16/XMODEM
+    assert val(pkg.chain.crc_bits(msg, 0x1864CFB, 24)) == 0xCDE703  # CRC-24/LTE-A
+    assert val(pkg.chain.crc_bits(msg, 0x1800063, 24)) == 0x23EF52  # CRC-24/LTE-B
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 24, 100, 1001):
+        a = rng.integers(0, 2, n, dtype=np.uint8)
+        for poly, L in ((0x11021, 16), (0x1864CFB, 24), (0x1800063, 24)):
+            full = np.concatenate([a, pkg.chain.crc_bits(a, poly, L)])
+            assert not pkg.chain.crc_bits(full, poly, L).any()  # detector sees zero syndrome
+            full[rng.integers(0, full.size)] ^= 1
+            assert pkg.chain.crc_bits(full, poly, L).any()
+
+
+def loop_bit_selection(p, r):
+    """Literal restatement of NRLDPCEncoder.m:186-195 (while loop, NaN skip)."""
+    Z, Kp, K, N_cb, k0, E = p.Z_c, int(p.K_prime), p.K, p.N_cb, p.k_0, p.E_r[r]
+    filler = np.zeros(p.N, bool)
+    filler[max(Kp - 2 * Z, 0): K - 2 * Z] = True
+    out, k, j = [], 0, 0
+    while k < E:
+        pos = (k0 + j) % N_cb
+        if not filler[pos]:
+            out.append(pos)
+            k += 1
+        j += 1
+    return np.array(out, np.int64)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(BG=2, A=100, G=300, Q_m=2), dict(BG=2, A=100, G=3000, Q_m=6, rv_id=2),
+    dict(BG=1, A=5000, G=6000, Q_m=4, rv_id=3), dict(BG=1, A=20016, G=60000, Q_m=8, N_L=2, rv_id=1),
+    dict(BG=2, A=3842, G=11526, Q_m=2, I_LBRM=1, TBS_LBRM=6000, rv_id=2)])
+def test_selection_and_interleave_maps(pkg, kw):
+    p = pkg.NRLDPC(**kw)
+    p.validate()
+    for r in range(p.C):
+        assert (pkg.chain.selection_index(p, r) == loop_bit_selection(p, r)).all()
+        E, Q = p.E_r[r], p.Q_m
+        e = np.arange(E)
+        f = np.zeros(E, np.int64)
+        for j in range(E // Q):       # NRLDPCEncoder.m:219-223
+            for i in range(Q):
+                f[i + j * Q] = e[i * (E // Q) + j]
+        fpos = pkg.chain.interleave_index(E, Q)
+        assert (f[fpos] == e).all()
+
+
+def test_rate_match_recover_round_trip_host(pkg):
+    """Encoder.rate_match then Decoder.rate_recover on +/-1 LLRs reproduces d (with repetition
+    soft-combining multiplicities) -- both are host logic, no device needed."""
+    kw = dict(BG=2, A=100, G=3000, Q_m=2)
+    enc, dec = pkg.NRLDPCEncoder(**kw), pkg.NRLDPCDecoder(**kw)
+    rng = np.random.default_rng(3)
+    d = rng.integers(0, 2, (enc.C, enc.N), dtype=np.uint8)
+    g = enc.rate_match(d, None)
+    dt = dec.rate_recover(1.0 - 2.0 * g)
+    Z, Kp = enc.Z_c, int(enc.K_prime)
+    fill = np.zeros(enc.N, bool)
+    fill[Kp - 2 * Z: enc.K - 2 * Z] = True
+    assert np.isnan(dt[0, fill]).all()
+    mult = np.bincount(pkg.chain.selection_index(enc, 0), minlength=enc.N)
+    assert (dt[0, ~fill] == ((1.0 - 2.0 * d[0]) * mult)[~fill]).all()
+    assert mult[~fill].min() >= 1 and mult.max() >= 2  # G=3000 > N: every position repeated

@@ -1,0 +1,152 @@
+"""GPU parity tests proper: the HIP decoder behind the C ABI vs the CPU oracle, bit-exact
+(integer algorithm: hard bits, iteration counts and soft outputs must all be identical)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ALL_Z, BG_DIMS, awgn_llr
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def run_case(pkg, orc, rng, bg, Z, B, esn0, iters, nl=0, et=True, dt=np.float16, alpha=0.75, scale=8, app=True):
+    kb = BG_DIMS[bg][2]
+    info = rng.integers(0, 2, (B, kb * Z), dtype=np.uint8)
+    cw = orc.encode(bg, Z, info)
+    llr = awgn_llr(rng, cw, esn0, dt, Z)
+    c = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, alpha=alpha, llr_scale=scale, llr_dtype=dt)
+    try:
+        out = c.decode(llr, want_iters=True, want_app=app)
+    finally:
+        c.close()
+    ref = orc.decode_nmsq(bg, Z, llr.astype(np.float64), iters, n_layers=nl, early_term=et, alpha=alpha,
+                          scale=scale, want_app=app)
+    assert (out[0] == ref[0]).all(), "hard decisions differ"
+    assert (out[1] == ref[1]).all(), "iteration counts differ"
+    if app:
+        assert (out[2] == ref[2]).all(), "soft outputs differ"
+    return out, info
+
+
+def test_loaded_library_is_the_in_tree_hip_build(pkg):
+    path = pkg._capi.lib_path()
+    assert path.endswith("libnrldpc_hip.so") and os.path.exists(path)
+    maps = open("/proc/self/maps").read()
+    pkg.load()
+    assert "libnrldpc_hip.so" in open("/proc/self/maps").read() or "libnrldpc_hip.so" in maps
+
+
+@pytest.mark.parametrize("bg", [1, 2])
+def test_every_lifting_size(pkg, orc, bg):
+    """All 51 Z of Table 5.3.2-1, both base graphs, ragged batches (not a multiple of codewords/workgroup)."""
+    rng = np.random.default_rng(1000 + bg)
+    for Z in ALL_Z:
+        B = 1 + int(rng.integers(0, 5)) + (768 // Z if Z < 64 else 0)
+        run_case(pkg, orc, rng, bg, Z, B, 2.0, 6, et=bool(Z & 2), dt=np.float32 if Z % 3 else np.float16)
+
+
+@pytest.mark.parametrize("bg,Z,nl,esn0", [(1, 384, 46, -0.8), (1, 384, 5, 6.2), (1, 384, 20, 1.0), (2, 384, 42, -1.0),
+                                          (2, 384, 7, 4.5), (2, 384, 22, 0.5), (1, 352, 30, 0.0), (2, 208, 21, 1.0),
+                                          (1, 64, 4, 8.0), (2, 20, 12, 2.0)])
+def test_rate_pruned_layers(pkg, orc, bg, Z, nl, esn0):
+    rng = np.random.default_rng(Z * 100 + nl)
+    run_case(pkg, orc, rng, bg, Z, 5, esn0, 12, nl=nl, et=True)
+    run_case(pkg, orc, rng, bg, Z, 3, esn0, 7, nl=nl, et=False)
+
+
+def test_per_iteration_soft_llrs(pkg, orc):
+    """Soft a-posteriori LLRs after 1, 2, ..., 8 iterations (tolerance: none, values are k/scale exactly)."""
+    rng = np.random.default_rng(77)
+    for bg, Z in ((1, 384), (2, 96)):
+        kb = BG_DIMS[bg][2]
+        info = rng.integers(0, 2, (2, kb * Z), dtype=np.uint8)
+        llr = awgn_llr(rng, orc.encode(bg, Z, info), -0.5, np.float32, Z)
+        for it in range(1, 9):
+            c = pkg.Codec(bg, Z, max_iter=it, early_term=False, llr_dtype=np.float32)
+            h, iters, app = c.decode(llr, want_iters=True, want_app=True)
+            c.close()
+            ho, io, ao = orc.decode_nmsq(bg, Z, llr.astype(np.float64), it, early_term=False, want_app=True)
+            assert (app == ao).all() and (h == ho).all() and (iters == it).all()
+
+
+@pytest.mark.parametrize("alpha,scale", [(0.625, 8), (0.6875, 16), (0.8, 4), (1.0, 8), (0.75, 32), (0.5, 1)])
+def test_alpha_and_scale(pkg, orc, alpha, scale):
+    rng = np.random.default_rng(int(alpha * 1000) + scale)
+    run_case(pkg, orc, rng, 1, 96, 4, 0.5, 10, alpha=alpha, scale=scale)
+    run_case(pkg, orc, rng, 2, 384, 2, 0.0, 6, alpha=alpha, scale=scale, et=False)
+
+
+def test_special_llr_values(pkg, orc):
+    """+inf fillers (NRLDPCDecoder.m:264), -inf, NaN, zeros, saturating magnitudes, all-zero input."""
+    rng = np.random.default_rng(5)
+    bg, Z, kb, Kp = 2, 20, 10, 116
+    info = rng.integers(0, 2, (6, kb * Z), dtype=np.uint8)
+    info[:, Kp:] = 0
+    cw = orc.encode(bg, Z, info)
+    llr = awgn_llr(rng, cw, 3.0, np.float32, Z, E=300)
+    llr[:, Kp: kb * Z] = np.inf
+    llr[1, 50] = np.nan
+    llr[2, 70] = -np.inf
+    llr[2, (kb + 6) * Z + 3] = np.inf
+    llr[3] *= 1000.0
+    llr[4] = 0.0
+    llr[5, ::3] = -0.0
+    for dt in (np.float32, np.float16, np.float64):
+        c = pkg.Codec(bg, Z, max_iter=10, n_layers=12, early_term=True, llr_dtype=dt)
+        h, it, app = c.decode(llr.astype(dt), want_iters=True, want_app=True)
+        c.close()
+        ho, io, ao = orc.decode_nmsq(bg, Z, llr.astype(dt).astype(np.float64), 10, n_layers=12, early_term=True,
+                                     want_app=True)
+        assert (h == ho).all() and (it == io).all() and (app == ao).all()
+        assert (h[0] == info[0]).all() and it[4] == 1 and not h[4].any()
+
+
+def test_golden_fixture_on_gpu(pkg):
+    g = np.load(os.path.join(GOLD, "nmsq_golden.npz"))
+    for name in sorted(set(k.split("/")[0] for k in g.files)):
+        bg, Z, nl, it, et, alpha, scale = (g[name + "/cfg"][i] for i in range(7))
+        c = pkg.Codec(int(bg), int(Z), max_iter=int(it), n_layers=int(nl), early_term=bool(et), alpha=float(alpha),
+                      llr_scale=int(scale), llr_dtype=np.float16)
+        h, iters, app = c.decode(g[name + "/llr"], want_iters=True, want_app=True)
+        cw = c.encode(g[name + "/info"])
+        c.close()
+        assert (np.packbits(h, axis=1) == g[name + "/hard_packed"]).all(), name
+        assert (iters == g[name + "/iters"]).all(), name
+        assert (app.astype(np.float16) == g[name + "/app_f16"]).all(), name
+        assert (np.packbits(cw, axis=1) == g[name + "/cw_packed"]).all(), name
+
+
+def test_empty_and_argument_errors(pkg):
+    c = pkg.Codec(1, 8, max_iter=3)
+    assert c.decode(np.zeros((0, c.N_cw), np.float32)).shape == (0, c.K)
+    with pytest.raises(pkg.NRLDPCError):
+        c.decode(np.zeros(c.N_cw + 1, np.float32))
+    with pytest.raises(pkg.NRLDPCError):
+        c.encode(np.zeros(c.K - 1, np.uint8))
+    c.close()
+    with pytest.raises(pkg.NRLDPCError):
+        pkg.Codec(1, 8, device_id=99)
+
+
+def test_device_pointer_entry_and_timing(pkg, orc):
+    import torch
+    rng = np.random.default_rng(9)
+    bg, Z, B = 1, 384, 64
+    info = rng.integers(0, 2, (B, 22 * Z), dtype=np.uint8)
+    llr = awgn_llr(rng, orc.encode(bg, Z, info), 0.0, np.float16, Z)
+    c = pkg.Codec(bg, Z, max_iter=10, early_term=True, llr_dtype=np.float16)
+    d_llr = torch.from_numpy(llr).cuda()
+    d_hard = torch.zeros((B, 22 * Z), dtype=torch.uint8, device="cuda")
+    d_it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    c.set_timing(True)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        c.decode_dev(d_llr.data_ptr(), B, d_hard.data_ptr(), d_it.data_ptr(), None, s.cuda_stream)
+    ms = c.last_kernel_ms()
+    s.synchronize()
+    ho, io = orc.decode_nmsq(bg, Z, llr.astype(np.float64), 10, early_term=True)
+    assert (d_hard.cpu().numpy() == ho).all() and (d_it.cpu().numpy() == io).all()
+    assert 0.0 < ms < 1000.0
+    c.close()

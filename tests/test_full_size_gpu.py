@@ -1,0 +1,87 @@
+"""BASELINE.json's full sizes through size-independent properties (the oracle would need minutes):
+encode -> noise -> decode round trips on 4096-codeword batches, agreement between the host and the
+device entry points, oracle spot checks on a sample, and the mixed-(BG,Z) configuration."""
+import numpy as np
+import pytest
+
+from conftest import ALL_Z, BG_DIMS, awgn_llr
+
+pytestmark = pytest.mark.gpu
+
+
+def _roundtrip(pkg, orc, bg, Z, B, nl, E, esn0, iters, et, seed):
+    rng = np.random.default_rng(seed)
+    kb = BG_DIMS[bg][2]
+    c = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, llr_dtype=np.float16,
+                  alpha=pkg.default_alpha(bg, nl or BG_DIMS[bg][0]))
+    info = rng.integers(0, 2, (B, kb * Z), dtype=np.uint8)
+    cw = c.encode(info)
+    llr = awgn_llr(rng, cw, esn0, np.float16, Z, E=E)
+    hard, it = c.decode(llr, want_iters=True)
+    c.close()
+    bler = float((hard != info).any(1).mean())
+    sample = rng.choice(B, 6, replace=False)
+    ho, io = orc.decode_nmsq(bg, Z, llr[sample].astype(np.float64), iters, n_layers=nl, early_term=et,
+                             alpha=pkg.default_alpha(bg, nl or BG_DIMS[bg][0]))
+    assert (hard[sample] == ho).all() and (it[sample] == io).all()
+    assert all(orc.syndrome_weight(bg, Z, cw[b]) == 0 for b in sample)
+    return bler, it
+
+
+def test_cfg2_bg1_z384_r13_batch4096(pkg, orc):
+    bler, it = _roundtrip(pkg, orc, 1, 384, 4096, 0, 25344, -0.6, 25, False, 1)
+    assert bler < 0.02 and (it == 25).all()
+
+
+def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):
+    # G for R = 1/5 ... 2/3 -> active layers; Es/N0 about 1 dB above each waterfall
+    for E, nl, esn0 in ((19120, 42, -3.0), (11472, 22, -0.5), (7648, 12, 2.0), (5736, 7, 4.5)):
+        bler, it = _roundtrip(pkg, orc, 2, 384, 4096, nl, E, esn0, 25, True, E)
+        assert bler < 0.05, (E, bler)
+        assert it.min() >= 1 and it.mean() < 20
+
+
+def test_cfg5_bg1_r89_early_termination_shard(pkg, orc):
+    """One GPU's shard (8192 codewords) of the 65536-codeword R=8/9 configuration."""
+    bler, it = _roundtrip(pkg, orc, 1, 384, 8192, 5, 9478, 7.5, 25, True, 5)
+    assert bler < 0.02 and it.mean() < 8
+
+
+def test_cfg4_mixed_bg_and_Z(pkg, orc):
+    """Mixed BG1/BG2, Z drawn per codeword: host buckets by (BG, Z), one launch per bucket."""
+    rng = np.random.default_rng(4)
+    draws = [(int(rng.integers(1, 3)), int(rng.choice(ALL_Z))) for _ in range(8192)]
+    buckets = {}
+    for i, key in enumerate(draws):
+        buckets.setdefault(key, []).append(i)
+    n_ok = n = 0
+    for (bg, Z), idx in sorted(buckets.items()):
+        kb = BG_DIMS[bg][2]
+        c = pkg.Codec(bg, Z, max_iter=25, early_term=True, llr_dtype=np.float16, alpha=0.625)
+        info = rng.integers(0, 2, (len(idx), kb * Z), dtype=np.uint8)
+        llr = awgn_llr(rng, c.encode(info), 3.0, np.float16, Z)
+        hard, it = c.decode(llr, want_iters=True)
+        c.close()
+        if Z >= 32:  # tiny codes have a real error rate at any SNR; count only the rest
+            n_ok += int((hard == info).all(1).sum())
+            n += len(idx)
+        j = int(rng.integers(0, len(idx)))
+        ho, io = orc.decode_nmsq(bg, Z, llr[j:j + 1].astype(np.float64), 25, early_term=True, alpha=0.625)
+        assert (hard[j] == ho[0]).all() and it[j] == io[0]
+    assert len(buckets) >= 90 and n_ok / n > 0.97
+
+
+def test_host_and_device_entry_points_agree(pkg, orc):
+    import torch
+    rng = np.random.default_rng(12)
+    c = pkg.Codec(2, 384, max_iter=25, n_layers=22, early_term=True, llr_dtype=np.float16)
+    info = rng.integers(0, 2, (4096, c.K), dtype=np.uint8)
+    llr = awgn_llr(rng, c.encode(info), 0.0, np.float16, 384, E=11472)
+    h1, it1 = c.decode(llr, want_iters=True)
+    d_llr = torch.from_numpy(llr).cuda()
+    d_h = torch.empty((4096, c.K), dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(4096, dtype=torch.int32, device="cuda")
+    c.decode_dev(d_llr.data_ptr(), 4096, d_h.data_ptr(), d_it.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    c.close()
+    assert (d_h.cpu().numpy() == h1).all() and (d_it.cpu().numpy() == it1).all()

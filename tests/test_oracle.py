@@ -1,0 +1,131 @@
+"""The oracle itself: encoder pinned by H*c = 0, decoders by round trips, and the C restatement of
+the build's algorithm cross-checked against an independent numpy restatement and committed fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ALL_Z, BG_DIMS, awgn_llr
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("bg", [1, 2])
+def test_encoder_parity_all_Z(orc, bg):
+    rng = np.random.default_rng(100 + bg)
+    kb = BG_DIMS[bg][2]
+    for Z in ALL_Z:
+        info = rng.integers(0, 2, (2, kb * Z), dtype=np.uint8)
+        cw = orc.encode(bg, Z, info)
+        assert (cw[:, : kb * Z] == info).all()
+        for b in range(2):
+            assert orc.syndrome_weight(bg, Z, cw[b]) == 0
+        # linearity: enc(a) ^ enc(b) = enc(a ^ b)
+        assert ((cw[0] ^ cw[1]) == orc.encode(bg, Z, info[0] ^ info[1])[0]).all()
+    assert orc.syndrome_weight(bg, 8, np.zeros(BG_DIMS[bg][1] * 8, np.uint8)) == 0
+
+
+def nmsq_numpy(bg, Z, llr, max_iter, n_layers, early_term, alpha, scale, orc):
+    """Independent restatement of NMS-Q (vectorised over z, written from the algorithm statement in
+    DESIGN.md, not from the C code)."""
+    nrows, ncols, kb = BG_DIMS[bg]
+    n_layers = n_layers or nrows
+    r_, c_, s_ = orc.graph_edges(bg, Z)
+    x = np.asarray(llr, np.float64)
+    q = np.where(np.isnan(x), 0.0, np.rint(np.clip(np.float32(x) * np.float32(scale), -127, 127))).astype(np.int64)
+    core = (np.arange(ncols * Z) // Z) < kb + 4
+    q = np.where(np.isinf(x), np.where(core, np.sign(x) * 2 ** 20, np.sign(x) * 127), q).astype(np.int64)
+    APP = q.copy()
+    msg = {}
+    zz = np.arange(Z)
+    it_done = max_iter
+    for it in range(1, max_iter + 1):
+        for l in range(n_layers):
+            es = np.nonzero(r_ == l)[0]
+            vidx = [c_[e] * Z + (zz + s_[e]) % Z for e in es]
+            t = np.stack([APP[v] - msg.get(e, 0) for e, v in zip(es, vidx)])
+            a = np.abs(t)
+            srt = np.sort(a, axis=0)
+            m1, m2 = srt[0], srt[1]
+            S = (t < 0).sum(0) & 1
+            M1 = np.minimum(np.rint(np.float32(alpha) * m1.astype(np.float32)), 127).astype(np.int64)
+            M2 = np.minimum(np.rint(np.float32(alpha) * m2.astype(np.float32)), 127).astype(np.int64)
+            for k, (e, v) in enumerate(zip(es, vidx)):
+                mag = np.where(a[k] == m1, M2, M1)
+                rr = np.where(((t[k] < 0) ^ (S == 1)), -mag, mag)
+                APP[v] = t[k] + rr
+                msg[e] = rr
+        if early_term:
+            bad = 0
+            for l in range(n_layers):
+                p = np.zeros(Z, np.int64)
+                for e in np.nonzero(r_ == l)[0]:
+                    p ^= (APP[c_[e] * Z + (zz + s_[e]) % Z] < 0)
+                bad += p.sum()
+            if bad == 0:
+                it_done = it
+                break
+    return (APP[: kb * Z] < 0).astype(np.uint8), it_done, (APP / scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("bg,Z,nl,et,alpha,scale,esn0", [
+    (1, 8, 0, False, 0.75, 8, 1.0), (1, 24, 10, True, 0.625, 16, 3.0), (2, 20, 0, True, 0.75, 8, 0.0),
+    (2, 6, 6, False, 0.8125, 4, 4.0), (1, 36, 46, True, 0.6875, 8, -1.0)])
+def test_nmsq_c_vs_numpy(orc, bg, Z, nl, et, alpha, scale, esn0):
+    rng = np.random.default_rng(7)
+    kb = BG_DIMS[bg][2]
+    info = rng.integers(0, 2, (3, kb * Z), dtype=np.uint8)
+    cw = orc.encode(bg, Z, info)
+    llr = awgn_llr(rng, cw, esn0, np.float32, Z).astype(np.float64)
+    llr[0, 5 * Z + 1] = np.inf
+    llr[1, 3 * Z] = np.nan
+    llr[2, (kb + 5) * Z] = -np.inf
+    h, it, app = orc.decode_nmsq(bg, Z, llr, 6, n_layers=nl, early_term=et, alpha=alpha, scale=scale, want_app=True)
+    for b in range(3):
+        hn, itn, appn = nmsq_numpy(bg, Z, llr[b], 6, nl, et, alpha, scale, orc)
+        assert (h[b] == hn).all() and it[b] == itn
+        assert (app[b] == appn).all()
+
+
+@pytest.mark.parametrize("bg,Z", [(1, 384), (2, 384), (1, 2), (2, 3), (1, 208), (2, 20)])
+def test_noise_free_round_trip(orc, bg, Z):
+    rng = np.random.default_rng(11)
+    kb = BG_DIMS[bg][2]
+    info = rng.integers(0, 2, (2, kb * Z), dtype=np.uint8)
+    cw = orc.encode(bg, Z, info)
+    llr = 10.0 * (1 - 2.0 * cw)
+    llr[:, : 2 * Z] = 0  # punctured columns are recovered by the decoder
+    h, it = orc.decode_nmsq(bg, Z, llr, 5, early_term=True)
+    assert (h == info).all() and (it <= 2).all()
+    h, it = orc.decode_bp_flood(bg, Z, llr, 5)
+    assert (h == info).all() and (it <= 3).all()
+
+
+def test_bp_and_nmsq_decode_awgn(orc):
+    """Both algorithms clear a comfortable SNR: BG2 Z=20 (cfg1: A=100 -> K'=116, 84 fillers), 10 iterations."""
+    rng = np.random.default_rng(5)
+    bg, Z, kb, Kp = 2, 20, 10, 116
+    info = rng.integers(0, 2, (40, kb * Z), dtype=np.uint8)
+    info[:, Kp:] = 0
+    cw = orc.encode(bg, Z, info)
+    llr = awgn_llr(rng, cw, 4.0, np.float64, Z, E=300)
+    llr[:, Kp: kb * Z] = np.inf  # fillers (NRLDPCDecoder.m:264)
+    h1, _ = orc.decode_nmsq(bg, Z, llr, 10, n_layers=12, early_term=True)
+    h2, _ = orc.decode_bp_flood(bg, Z, llr, 10)
+    assert ((h1 != info).any(1)).mean() < 0.2 and ((h2 != info).any(1)).mean() < 0.2
+
+
+def test_golden_fixture(orc):
+    """Committed input/output vectors (generated by tests/golden/make_golden.py from the oracle; the
+    reference holds no decoder vectors -- 'parity unpinned')."""
+    g = np.load(os.path.join(GOLD, "nmsq_golden.npz"))
+    for name in sorted(set(k.split("/")[0] for k in g.files)):
+        bg, Z, nl, it, et, alpha, scale = (g[name + "/cfg"][i] for i in range(7))
+        h, iters, app = orc.decode_nmsq(int(bg), int(Z), g[name + "/llr"].astype(np.float64), int(it),
+                                        n_layers=int(nl), early_term=bool(et), alpha=float(alpha),
+                                        scale=int(scale), want_app=True)
+        assert (np.packbits(h, axis=1) == g[name + "/hard_packed"]).all()
+        assert (iters == g[name + "/iters"]).all()
+        assert (app.astype(np.float16) == g[name + "/app_f16"]).all()
+        cw = orc.encode(int(bg), int(Z), g[name + "/info"])
+        assert (np.packbits(cw, axis=1) == g[name + "/cw_packed"]).all()
