@@ -7,8 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libnrldpc_hip.so")
-SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_capi.hip"]
-HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h"]
+SOURCES = ["nrldpc_decode.hip", "nrldpc_decode_z64.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip",
+           "nrldpc_crc.hip", "nrldpc_capi.hip"]
+HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h"]
 
 
 def _hipcc():

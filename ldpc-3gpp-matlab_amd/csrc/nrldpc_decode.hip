@@ -19,112 +19,9 @@
 //   * all values are integers carried in fp32 (exact below 2^24), so abs/neg modifiers, v_med3_f32
 //     and v_min_f32 do the min-sum in 8 VALU ops per edge for pass 1 and 7 for pass 2.
 // HBM sees each codeword once on the way in (ncols*Z LLRs) and K hard bits on the way out.
-#include <hip/hip_runtime.h>
-#include <hip/hip_fp16.h>
-#include <stdint.h>
-
-#include <type_traits>
-#include <utility>
-
-#include "nr_bg_tables.h"
-#include "nrldpc_kernels.h"
+#include "nrldpc_device.h"
 
 namespace nrldpc {
-
-template <int BG> struct BGT;
-template <> struct BGT<1> {
-    static constexpr int ROWS = NR_BG1_ROWS, COLS = NR_BG1_COLS, KB = 22, NNZ = NR_BG1_NNZ;
-    static constexpr int row_ptr(int r) { return nr_bg1_row_ptr[r]; }
-    static constexpr int col(int e) { return nr_bg1_col[e]; }
-};
-template <> struct BGT<2> {
-    static constexpr int ROWS = NR_BG2_ROWS, COLS = NR_BG2_COLS, KB = 10, NNZ = NR_BG2_NNZ;
-    static constexpr int row_ptr(int r) { return nr_bg2_row_ptr[r]; }
-    static constexpr int col(int e) { return nr_bg2_col[e]; }
-};
-template <int BG> struct BGD : BGT<BG> {
-    static constexpr int NC = BGT<BG>::KB + 4;                    // core columns (LDS resident)
-    static constexpr int NCP = NC | 1;                            // odd dword stride
-    static constexpr int NEXT = BGT<BG>::ROWS - 4;                // extension rows / columns
-    static constexpr int NCORE = BGT<BG>::NNZ - NEXT;             // core edges (messages stored)
-    static constexpr int NW = (NCORE + 3) / 4;                    // message registers
-    static constexpr int NXW = (NEXT + 3) / 4;                    // extension-LLR registers
-    // number of core edges before row L (every row >= 4 carries exactly one extension edge, last)
-    static constexpr int core_base(int L) { return BGT<BG>::row_ptr(L) - (L > 4 ? L - 4 : 0); }
-};
-
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ uint32_t fbits(float x) { return __float_as_uint(x); }
-
-// Schedule tables are read through the constant address space so that every access is a scalar
-// (s_load) instruction: the index is compile-time, the base wave-uniform.
-typedef const int32_t __attribute__((address_space(4))) * ctab_t;
-__device__ __forceinline__ ctab_t as_ctab(const int32_t* p) { return reinterpret_cast<ctab_t>(reinterpret_cast<uintptr_t>(p)); }
-// Opaque identity on a wave-uniform value: stops LLVM hoisting iteration-invariant scalar loads,
-// write addresses and layer predicates out of the iteration loop (which costs >230 VGPRs + SGPR spills).
-__device__ __forceinline__ ctab_t launder(ctab_t p) {
-    uintptr_t v = reinterpret_cast<uintptr_t>(p);
-    asm volatile("" : "+s"(v));
-    return reinterpret_cast<ctab_t>(v);
-}
-__device__ __forceinline__ int launder(int v) {
-    asm volatile("" : "+s"(v));
-    return v;
-}
-
-// signed byte B of w -> float (one SDWA VALU op)
-template <int B> __device__ __forceinline__ float byte_to_f32(uint32_t w) {
-    float f;
-    if constexpr (B == 0)
-        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(f) : "v"(w));
-    else if constexpr (B == 1)
-        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(f) : "v"(w));
-    else if constexpr (B == 2)
-        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f) : "v"(w));
-    else
-        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(f) : "v"(w));
-    return f;
-}
-// (int)r -> byte B of w, other bytes preserved (one SDWA VALU op); r is an integer-valued float in [-127,127]
-template <int B> __device__ __forceinline__ void f32_to_byte(uint32_t& w, float r) {
-    if constexpr (B == 0)
-        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
-    else if constexpr (B == 1)
-        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
-    else if constexpr (B == 2)
-        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
-    else
-        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
-}
-
-template <int DT> __device__ __forceinline__ float load_llr(const void* p, size_t i) {
-    if constexpr (DT == NRLDPC_K_F16)
-        return __half2float(static_cast<const __half*>(p)[i]);
-    else
-        return static_cast<const float*>(p)[i];
-}
-
-// channel LLR -> fixed-point grid (integer-valued float).  Mirrors ingest() of the oracle.
-__device__ __forceinline__ float ingest(float x, float scale, bool core) {
-    float y = x * scale;
-    y = (y != y) ? 0.0f : y;
-    y = fminf(fmaxf(y, -127.0f), 127.0f);
-    y = rintf(y) + 0.0f; // +0.0f canonicalises -0
-    if (core && fabsf(x) == __builtin_inff()) y = copysignf(1048576.0f, x);
-    return y;
-}
-
-template <int BG> struct DecState {
-    uint32_t rm[BGD<BG>::NW];  // check-to-variable messages, int8 x4
-    uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4
-};
 
 // One base-graph layer for this thread's check row.  With ncw codewords per workgroup the LDS ring of a
 // column has ncw*Z slots, slot u = z*ncw + cwl; rotating z by P is rotating u by P*ncw, so the same
@@ -169,22 +66,24 @@ __device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zb, 
         m1 = fminf(m1, al);
         S ^= fbits(lam);
     }
-    const float M1 = fminf(rintf(a.alpha * m1), 127.0f);
-    const float M2 = fminf(rintf(a.alpha * m2), 127.0f);
+    // magnitudes carrying the row's sign parity; the edge's own sign is xor-ed in per edge
+    const uint32_t Sm = S & 0x80000000u;
+    const float M1 = __uint_as_float(fbits(fminf(rintf(a.alpha * m1), 127.0f)) | Sm);
+    const float M2 = __uint_as_float(fbits(fminf(rintf(a.alpha * m2), 127.0f)) | Sm);
     static_for<ncore>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);
         constexpr int ce = ce0 + j;
         const float tj = t[j];
         const float mag = (fabsf(tj) == m1) ? M2 : M1;
-        const float r = __uint_as_float(fbits(mag) | ((S ^ fbits(tj)) & 0x80000000u));
+        const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
         f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
         *reinterpret_cast<float*>(lds + ad[j] + 4 * c) = tj + r;
     });
     if constexpr (HAS_EXT) {
         if (a.need_ext) { // early termination and/or soft output: a-posteriori value of the extension bit
             const float mag = (fabsf(lam) == m1) ? M2 : M1;
-            const float r = __uint_as_float(fbits(mag) | ((S ^ fbits(lam)) & 0x80000000u));
+            const float r = __uint_as_float(fbits(mag) ^ (fbits(lam) & 0x80000000u));
             const float ae = lam + r;
             // esign is cleared at the start of every iteration, so a plain OR rebuilds bit L-4
             if constexpr (L - 4 < 32) esign_lo |= (fbits(ae) >> 31) << (L - 4);
@@ -287,7 +186,10 @@ __global__ __launch_bounds__(768) void nrldpc_decode_kernel(const DecArgs a, con
             constexpr int L = decltype(lc)::value;
             if (L < launder(a.n_layers)) {
                 if (!done) layer<BG, L>(st, lds, zb, a, rot, esign_lo, esign_hi, app_row);
-                __syncthreads();
+            }
+            if constexpr (LayerGroups<BG>::group_end(L)) { // see LayerGroups: one barrier per column-disjoint group
+                constexpr int gs = LayerGroups<BG>::group_start(L); // forced compile-time evaluation
+                if (gs < launder(a.n_layers)) __syncthreads();
             }
         });
         if (a.early_term) {
@@ -330,6 +232,7 @@ template <int BG, int DT> static hipError_t launch_t(const DecArgs& a, int grid,
 }
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
+    if (a.Z == 384) return launch_decode_z384(bg, a, stream);
     const int grid = (a.batch + a.ncw - 1) / a.ncw;
     const bool f16 = a.llr_kind == NRLDPC_K_F16;
     if (bg == 1)

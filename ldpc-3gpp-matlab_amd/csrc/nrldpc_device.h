@@ -1,0 +1,139 @@
+// nrldpc_device.h -- device-side helpers shared by the decoder kernels (gfx950).
+#ifndef NRLDPC_DEVICE_H
+#define NRLDPC_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "nr_bg_tables.h"
+#include "nrldpc_kernels.h"
+
+namespace nrldpc {
+
+template <int BG> struct BGT;
+template <> struct BGT<1> {
+    static constexpr int ROWS = NR_BG1_ROWS, COLS = NR_BG1_COLS, KB = 22, NNZ = NR_BG1_NNZ;
+    static constexpr int row_ptr(int r) { return nr_bg1_row_ptr[r]; }
+    static constexpr int col(int e) { return nr_bg1_col[e]; }
+};
+template <> struct BGT<2> {
+    static constexpr int ROWS = NR_BG2_ROWS, COLS = NR_BG2_COLS, KB = 10, NNZ = NR_BG2_NNZ;
+    static constexpr int row_ptr(int r) { return nr_bg2_row_ptr[r]; }
+    static constexpr int col(int e) { return nr_bg2_col[e]; }
+};
+template <int BG> struct BGD : BGT<BG> {
+    static constexpr int NC = BGT<BG>::KB + 4;                    // core columns (LDS resident)
+    static constexpr int NCP = NC | 1;                            // odd dword stride
+    static constexpr int NEXT = BGT<BG>::ROWS - 4;                // extension rows / columns
+    static constexpr int NCORE = BGT<BG>::NNZ - NEXT;             // core edges (messages stored)
+    static constexpr int NW = (NCORE + 3) / 4;                    // message registers
+    static constexpr int NXW = (NEXT + 3) / 4;                    // extension-LLR registers
+    // number of core edges before row L (every row >= 4 carries exactly one extension edge, last)
+    static constexpr int core_base(int L) { return BGT<BG>::row_ptr(L) - (L > 4 ? L - 4 : 0); }
+};
+
+// Barrier groups.  Layer L only needs a workgroup barrier in front of it if it shares a core column with
+// a layer processed since the last barrier: column-disjoint layers touch disjoint LDS words, so running
+// them back to back is exactly the sequential schedule.  From row ~20 on, consecutive rows of both base
+// graphs alternate between column 0 and column 1 and are otherwise sparse, which pairs them up: BG1 needs
+// 32 barriers per iteration instead of 46, BG2 28 instead of 42.  Groups are formed greedily in table
+// order (the processing order is NOT changed).
+template <int BG> struct LayerGroups {
+    using G = BGD<BG>;
+    static constexpr unsigned long long colmask(int L) {
+        unsigned long long m = 0;
+        for (int e = G::row_ptr(L); e < G::row_ptr(L + 1); ++e)
+            if (G::col(e) < G::NC) m |= 1ull << G::col(e);
+        return m;
+    }
+    // first layer of the group that contains layer L
+    static constexpr int group_start(int L) {
+        int start = 0;
+        unsigned long long acc = 0;
+        for (int l = 0; l <= L; ++l) {
+            const unsigned long long m = colmask(l);
+            if (acc & m) { start = l; acc = m; } else acc |= m;
+        }
+        return start;
+    }
+    static constexpr bool group_end(int L) { return L + 1 >= G::ROWS || group_start(L + 1) == L + 1; }
+};
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __float_as_uint(x); }
+
+// Schedule tables are read through the constant address space so that every access is a scalar
+// (s_load) instruction: the index is compile-time, the base wave-uniform.
+typedef const int32_t __attribute__((address_space(4))) * ctab_t;
+__device__ __forceinline__ ctab_t as_ctab(const int32_t* p) { return reinterpret_cast<ctab_t>(reinterpret_cast<uintptr_t>(p)); }
+// Opaque identity on a wave-uniform value: stops LLVM hoisting iteration-invariant scalar loads,
+// write addresses and layer predicates out of the iteration loop (which costs >230 VGPRs + SGPR spills).
+__device__ __forceinline__ ctab_t launder(ctab_t p) {
+    uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    asm volatile("" : "+s"(v));
+    return reinterpret_cast<ctab_t>(v);
+}
+__device__ __forceinline__ int launder(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// signed byte B of w -> float (one SDWA VALU op)
+template <int B> __device__ __forceinline__ float byte_to_f32(uint32_t w) {
+    float f;
+    if constexpr (B == 0)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(f) : "v"(w));
+    else if constexpr (B == 1)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(f) : "v"(w));
+    else if constexpr (B == 2)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f) : "v"(w));
+    else
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(f) : "v"(w));
+    return f;
+}
+// (int)r -> byte B of w, other bytes preserved (one SDWA VALU op); r is an integer-valued float in [-127,127]
+template <int B> __device__ __forceinline__ void f32_to_byte(uint32_t& w, float r) {
+    if constexpr (B == 0)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
+    else if constexpr (B == 1)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
+    else if constexpr (B == 2)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
+    else
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(r));
+}
+
+template <int DT> __device__ __forceinline__ float load_llr(const void* p, size_t i) {
+    if constexpr (DT == NRLDPC_K_F16)
+        return __half2float(static_cast<const __half*>(p)[i]);
+    else
+        return static_cast<const float*>(p)[i];
+}
+
+// channel LLR -> fixed-point grid (integer-valued float).  Mirrors ingest() of the oracle.
+__device__ __forceinline__ float ingest(float x, float scale, bool core) {
+    float y = x * scale;
+    y = (y != y) ? 0.0f : y;
+    y = fminf(fmaxf(y, -127.0f), 127.0f);
+    y = rintf(y) + 0.0f; // +0.0f canonicalises -0
+    if (core && fabsf(x) == __builtin_inff()) y = copysignf(1048576.0f, x);
+    return y;
+}
+
+template <int BG> struct DecState {
+    uint32_t rm[BGD<BG>::NW];  // check-to-variable messages, int8 x4
+    uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4
+};
+
+} // namespace nrldpc
+#endif

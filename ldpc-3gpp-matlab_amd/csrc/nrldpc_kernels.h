@@ -21,6 +21,7 @@ struct DecArgs {
 };
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_decode_z384(int bg, const DecArgs& a, hipStream_t stream); // compile-time-Z specialisation
 
 struct EncArgs {
     const uint8_t* info; // [batch][kb*Z]
