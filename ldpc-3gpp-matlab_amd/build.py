@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-LIB = os.path.join(HERE, "libnrldpc_hip.so")
+LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip.so")  # env override: kernel experiments
 SOURCES = ["nrldpc_decode.hip", "nrldpc_decode_z64.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip",
            "nrldpc_crc.hip", "nrldpc_capi.hip"]
 HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h"]

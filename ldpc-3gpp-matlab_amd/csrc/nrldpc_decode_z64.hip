@@ -41,87 +41,131 @@ template <int BG, int ZC, int NCWG_ = 768 / ZC> struct Z64 : BGD<BG> {
     static constexpr int NCWG = NCWG_;                  // codewords per workgroup
     static constexpr int ILS = z64_set_index(ZC);
     static constexpr int shift(int e) { return (BG == 1 ? nr_bg1_shift[ILS][e] : nr_bg2_shift[ILS][e < NR_BG2_NNZ ? e : 0]) % ZC; }
+    // Mirror coherence analysis (all layers active).  After edge e rewrites its column, ring words i >= kb_e
+    // are fresh in the primary copy of block 0 and words i < kb_e are fresh in the mirror.  The next edge on
+    // the same column (cyclic layer order) reads words i >= kb' from the primary copy and words i < kb' from
+    // the mirror, so exactly one twin write is owed: mirror -> primary ("A") if kb' < kb_e, primary ->
+    // mirror ("B") if kb' > kb_e, none if equal.
+    static constexpr int next_on_column(int e) {
+        const int c = BGD<BG>::col(e);
+        for (int i = e + 1; i < BGD<BG>::NNZ; ++i)
+            if (BGD<BG>::col(i) == c) return i;
+        for (int i = 0; i < e; ++i)
+            if (BGD<BG>::col(i) == c) return i;
+        return e;
+    }
+    // The last writer of a column in an iteration makes both copies fresh: the parity check, the soft
+    // output and the hard decision read the column through every edge / through the primary copy.
+    static constexpr bool last_on_column(int e) { return next_on_column(e) <= e; }
+    static constexpr bool twin_a(int e, bool full) {
+        return shift(e) % 64 != 0 && (!full || last_on_column(e) || shift(next_on_column(e)) % 64 < shift(e) % 64);
+    }
+    static constexpr bool twin_b(int e, bool full) {
+        return !full || last_on_column(e) || shift(next_on_column(e)) % 64 > shift(e) % 64;
+    }
     // + one trailing guard (the last column's block-0 twin write overshoots into it) + termination flags
     static constexpr size_t lds_bytes() { return (size_t)NCWG * CWS + GUARD + 16 * ((NCWG + 1 + 3) / 4); }
 };
 
-template <int BG, int ZC, int L>
-__device__ __forceinline__ void layer_z64(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], uint32_t RA,
-                                          uint32_t RB, int w, const DecArgs& a, uint32_t& esign_lo,
-                                          uint32_t& esign_hi, float* app_ext) {
-    using G = Z64<BG, ZC>;
-    constexpr int e0 = G::row_ptr(L);
-    constexpr int deg = G::row_ptr(L + 1) - e0;
-    constexpr bool HAS_EXT = (L >= 4);
-    constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
-    constexpr int ce0 = G::core_base(L);
-
-    float t[ncore];
-    float m1 = __builtin_inff(), m2 = __builtin_inff();
-    uint32_t S = 0;
-    static_for<ncore>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int c = G::col(e0 + j);
-        constexpr int ce = ce0 + j;
-        constexpr int P = G::shift(e0 + j);
-        constexpr int off = c * G::CS + 4 * (P % 64);
-        const float app = *reinterpret_cast<const float*>(lds + R[P / 64] + off);
-        const float r = byte_to_f32<ce & 3>(st.rm[ce >> 2]);
-        const float tj = app - r;
-        t[j] = tj;
-        const float aj = fabsf(tj);
-        m2 = __builtin_amdgcn_fmed3f(aj, m1, m2);
-        m1 = fminf(m1, aj);
-        S ^= fbits(tj);
-    });
-    float lam = 0.0f;
-    if constexpr (HAS_EXT) {
-        lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
-        const float al = fabsf(lam);
-        m2 = __builtin_amdgcn_fmed3f(al, m1, m2);
-        m1 = fminf(m1, al);
-        S ^= fbits(lam);
+// binary decision tree on the (wave-uniform) wave index: at most ceil(log2(HI-LO)) scalar branches
+template <int LO, int HI, class F> __device__ __forceinline__ void dispatch_w(int w, F&& f) {
+    if constexpr (HI - LO == 1) {
+        f(std::integral_constant<int, LO>{});
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (w < MID) dispatch_w<LO, MID>(w, f);
+        else dispatch_w<MID, HI>(w, f);
     }
-    const uint32_t Sm = S & 0x80000000u;
-    const float M1 = __uint_as_float(fbits(fminf(rintf(a.alpha * m1), 127.0f)) | Sm);
-    const float M2 = __uint_as_float(fbits(fminf(rintf(a.alpha * m2), 127.0f)) | Sm);
-    static_for<ncore>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int c = G::col(e0 + j);
-        constexpr int ce = ce0 + j;
-        constexpr int P = G::shift(e0 + j);
-        constexpr int ka = P / 64, kb = P % 64;
-        constexpr int off = c * G::CS + 4 * kb;
-        const float tj = t[j];
-        const float mag = (fabsf(tj) == m1) ? M2 : M1;
-        const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
-        f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
-        const float v = tj + r;
-        t[j] = v; // kept for the mirror pass below
-        *reinterpret_cast<float*>(lds + R[ka] + off) = v;
-    });
-    // Mirror coherence (ring block 0 lives at ring words [0,64) and again at [ZC, ZC+64)), grouped by the
-    // wave that owes the twin write so that each wave takes at most one taken branch per layer:
+}
+
+// One base-graph layer for this thread's check row, split into phases so that the layers of a
+// column-disjoint barrier group can issue all their LDS reads first and share one mirror dispatch.
+template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
+    using G = Z64<BG, ZC>;
+    static constexpr int e0 = G::row_ptr(L);
+    static constexpr int deg = G::row_ptr(L + 1) - e0;
+    static constexpr bool HAS_EXT = (L >= 4);
+    static constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
+    static constexpr int ce0 = G::core_base(L);
+    float t[ncore];
+    float lam, m1, M1, M2;
+
+    __device__ __forceinline__ void load(const char* lds, const uint32_t (&R)[ZC / 64]) {
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int P = G::shift(e0 + j);
+            t[j] = *reinterpret_cast<const float*>(lds + R[P / 64] + G::col(e0 + j) * G::CS + 4 * (P % 64));
+        });
+    }
+
+    __device__ __forceinline__ void update(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
+        float mm1 = __builtin_inff(), mm2 = __builtin_inff();
+        uint32_t S = 0;
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int ce = ce0 + j;
+            const float tj = t[j] - byte_to_f32<ce & 3>(st.rm[ce >> 2]);
+            t[j] = tj;
+            const float aj = fabsf(tj);
+            mm2 = __builtin_amdgcn_fmed3f(aj, mm1, mm2);
+            mm1 = fminf(mm1, aj);
+            S ^= fbits(tj);
+        });
+        lam = 0.0f;
+        if constexpr (HAS_EXT) {
+            lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
+            const float al = fabsf(lam);
+            mm2 = __builtin_amdgcn_fmed3f(al, mm1, mm2);
+            mm1 = fminf(mm1, al);
+            S ^= fbits(lam);
+        }
+        m1 = mm1;
+        // magnitudes carrying the row's sign parity; the edge's own sign is xor-ed in per edge
+        const uint32_t Sm = S & 0x80000000u;
+        M1 = __uint_as_float(fbits(fminf(rintf(a.alpha * mm1), 127.0f)) | Sm);
+        M2 = __uint_as_float(fbits(fminf(rintf(a.alpha * mm2), 127.0f)) | Sm);
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int ce = ce0 + j;
+            constexpr int P = G::shift(e0 + j);
+            const float tj = t[j];
+            const float mag = (fabsf(tj) == m1) ? M2 : M1;
+            const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
+            f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
+            const float v = tj + r;
+            t[j] = v; // kept for the mirror pass
+            *reinterpret_cast<float*>(lds + R[P / 64] + G::col(e0 + j) * G::CS + 4 * (P % 64)) = v;
+        });
+    }
+
+    // Mirror coherence (ring block 0 lives at ring words [0,64) and again at [ZC, ZC+64)) owed by wave WV:
     //   wave (NWV-1-ka): its run started in the last block and ran into the mirror -> twin at RA + off
     //   wave (NWV-ka)  : its run started in block 0                                -> twin at RB + off
-    static_for<G::NWV>([&](auto wc) {
-        constexpr int wv = decltype(wc)::value;
-        if (w == wv) {
-            static_for<ncore>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                constexpr int c = G::col(e0 + j);
-                constexpr int P = G::shift(e0 + j);
-                constexpr int ka = P / 64, kb = P % 64;
-                constexpr int off = c * G::CS + 4 * kb;
-                if constexpr (kb != 0 && wv == (2 * G::NWV - 1 - ka) % G::NWV)
-                    *reinterpret_cast<float*>(lds + RA + off) = t[j];
-                if constexpr (wv == (G::NWV - ka) % G::NWV)
-                    *reinterpret_cast<float*>(lds + RB + off) = t[j];
-            });
-        }
-    });
-    if constexpr (HAS_EXT) {
-        if (a.need_ext) {
+    // With every layer active (FULL) the next reader of the column is known at compile time and only the
+    // twin it will actually read is written (Z64::twin_a/twin_b); with pruned layers both are.
+    template <int WV> __device__ __forceinline__ void twins(char* lds, uint32_t RA, uint32_t RB) const {
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int P = G::shift(e0 + j);
+            constexpr int ka = P / 64;
+            constexpr int off = G::col(e0 + j) * G::CS + 4 * (P % 64);
+            if constexpr ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
+                          (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV)) {
+                // opaque copy: stops SimplifyCFG sinking the per-wave stores into one store that indexes t[]
+                // dynamically (which would push t[] to scratch)
+                float v = t[j];
+                asm volatile("" : "+v"(v));
+                if constexpr (G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV)
+                    *reinterpret_cast<float*>(lds + RA + off) = v;
+                if constexpr (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV)
+                    *reinterpret_cast<float*>(lds + RB + off) = v;
+            }
+        });
+    }
+
+    // early termination / soft output need the a-posteriori value of the row's extension-parity bit
+    __device__ __forceinline__ void ext(const DecArgs& a, uint32_t& esign_lo, uint32_t& esign_hi, float* app_ext) const {
+        if constexpr (HAS_EXT) {
             const float mag = (fabsf(lam) == m1) ? M2 : M1;
             const float r = __uint_as_float(fbits(mag) ^ (fbits(lam) & 0x80000000u));
             const float ae = lam + r;
@@ -133,6 +177,36 @@ __device__ __forceinline__ void layer_z64(DecState<BG>& st, char* lds, const uin
                 p[(size_t)(G::NC + L - 4) * ZC] = ae * a.inv_scale;
             }
         }
+    }
+};
+
+// Layers GS..GE (a column-disjoint barrier group, see LayerGroups) processed as one block of code.
+template <int BG, int ZC, int GS, int GE, bool FULL>
+__device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], uint32_t RA,
+                                          uint32_t RB, int w, const DecArgs& a, uint32_t& esign_lo,
+                                          uint32_t& esign_hi, float* app_ext) {
+    constexpr int N = GE - GS + 1;
+    static_assert(N >= 1 && N <= 3, "group size");
+    constexpr int NWV = ZC / 64;
+    LayerZ64<BG, ZC, GS, FULL> l0;
+    LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), FULL> l1;
+    LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), FULL> l2;
+    l0.load(lds, R);
+    if constexpr (N > 1) l1.load(lds, R);
+    if constexpr (N > 2) l2.load(lds, R);
+    l0.update(st, lds, R, a);
+    if constexpr (N > 1) l1.update(st, lds, R, a);
+    if constexpr (N > 2) l2.update(st, lds, R, a);
+    dispatch_w<0, NWV>(w, [&](auto wc) {
+        constexpr int WV = decltype(wc)::value;
+        l0.template twins<WV>(lds, RA, RB);
+        if constexpr (N > 1) l1.template twins<WV>(lds, RA, RB);
+        if constexpr (N > 2) l2.template twins<WV>(lds, RA, RB);
+    });
+    if (a.need_ext) {
+        l0.ext(a, esign_lo, esign_hi, app_ext);
+        if constexpr (N > 1) l1.ext(a, esign_lo, esign_hi, app_ext);
+        if constexpr (N > 2) l2.ext(a, esign_lo, esign_hi, app_ext);
     }
 }
 
@@ -156,8 +230,8 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
     return p;
 }
 
-template <int BG, int ZC, int NCWG>
-__global__ __launch_bounds__(NCWG * ZC, 4) void nrldpc_decode_z64_kernel(const DecArgs a) {
+template <int BG, int ZC, int NCWG, bool FULL>
+__global__ __launch_bounds__(NCWG * ZC, (NCWG * ZC) / 256) void nrldpc_decode_z64_kernel(const DecArgs a) {
     using G = Z64<BG, ZC, NCWG>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -233,12 +307,28 @@ __global__ __launch_bounds__(NCWG * ZC, 4) void nrldpc_decode_z64_kernel(const D
         if (!done) { esign_lo = 0; esign_hi = 0; }
         static_for<G::ROWS>([&](auto lc) {
             constexpr int L = decltype(lc)::value;
-            if (L < launder(a.n_layers)) {
-                if (!done) layer_z64<BG, ZC, L>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
-            }
-            if constexpr (LayerGroups<BG>::group_end(L)) { // see LayerGroups: one barrier per column-disjoint group
-                constexpr int gs = LayerGroups<BG>::group_start(L); // forced compile-time evaluation
-                if (gs < launder(a.n_layers)) __syncthreads();
+            using LG = LayerGroups<BG>;
+            if constexpr (LG::group_start(L) == L) { // L leads a barrier group
+                constexpr int GE = LG::group_last(L);
+                if constexpr (FULL) { // every layer active: no per-layer predicates at all
+                    if (!done) group_z64<BG, ZC, L, GE, FULL>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
+                    __syncthreads();
+                } else {
+                    const int nl = launder(a.n_layers);
+                    if (L < nl) {
+                        if (!done) {
+                            if (GE < nl) {
+                                group_z64<BG, ZC, L, GE, FULL>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
+                            } else { // the layer count cuts this group: its active layers one by one
+                                static_for<GE - L>([&](auto ic) {
+                                    constexpr int LL = L + decltype(ic)::value;
+                                    if (LL < nl) group_z64<BG, ZC, LL, LL, FULL>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
+                                });
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
             }
         });
         if (a.early_term) {
@@ -271,9 +361,9 @@ __global__ __launch_bounds__(NCWG * ZC, 4) void nrldpc_decode_z64_kernel(const D
     }
 }
 
-template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
+template <int BG, int ZC, int NCWG, bool FULL> static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
     using G = Z64<BG, ZC, NCWG>;
-    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG>;
+    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -283,11 +373,14 @@ template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& 
     return hipGetLastError();
 }
 
+template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
+    return a.n_layers == BGD<BG>::ROWS ? launch_z64f<BG, ZC, NCWG, true>(a, s) : launch_z64f<BG, ZC, NCWG, false>(a, s);
+}
+
 hipError_t launch_decode_z384(int bg, const DecArgs& a, hipStream_t stream) {
-    // Codewords per workgroup: 2 (12 waves, three per SIMD, one workgroup per CU) measured faster than 1
-    // (two independent 6-wave workgroups per CU).  NRLDPC_Z384_NCWG=1 selects the latter for experiments.
-    static const int ncwg = [] { const char* e = getenv("NRLDPC_Z384_NCWG"); return (e && e[0] == '1') ? 1 : 2; }();
-    if (ncwg == 1) return bg == 1 ? launch_z64<1, 384, 1>(a, stream) : launch_z64<2, 384, 1>(a, stream);
+    // Two codewords (12 waves, three per SIMD) per workgroup, one workgroup per CU.  One codeword per
+    // workgroup with two workgroups per CU measured 15 % slower: the dispatcher leaves the second slot of a
+    // CU empty ~15-20 % of the time (tools/ubench/occ_probe.hip).
     return bg == 1 ? launch_z64<1, 384, 2>(a, stream) : launch_z64<2, 384, 2>(a, stream);
 }
 

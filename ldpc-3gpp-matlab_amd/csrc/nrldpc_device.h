@@ -60,6 +60,11 @@ template <int BG> struct LayerGroups {
         return start;
     }
     static constexpr bool group_end(int L) { return L + 1 >= G::ROWS || group_start(L + 1) == L + 1; }
+    static constexpr int group_last(int L) {
+        int l = L;
+        while (!group_end(l)) ++l;
+        return l;
+    }
 };
 
 template <class F, int... I>
