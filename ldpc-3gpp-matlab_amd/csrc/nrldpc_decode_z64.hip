@@ -181,7 +181,7 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
 };
 
 // Layers GS..GE (a column-disjoint barrier group, see LayerGroups) processed as one block of code.
-template <int BG, int ZC, int GS, int GE, bool FULL>
+template <int BG, int ZC, int GS, int GE, bool FULL, bool PLAIN>
 __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], uint32_t RA,
                                           uint32_t RB, int w, const DecArgs& a, uint32_t& esign_lo,
                                           uint32_t& esign_hi, float* app_ext) {
@@ -203,7 +203,7 @@ __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uin
         if constexpr (N > 1) l1.template twins<WV>(lds, RA, RB);
         if constexpr (N > 2) l2.template twins<WV>(lds, RA, RB);
     });
-    if (a.need_ext) {
+    if constexpr (!PLAIN) if (a.need_ext) {
         l0.ext(a, esign_lo, esign_hi, app_ext);
         if constexpr (N > 1) l1.ext(a, esign_lo, esign_hi, app_ext);
         if constexpr (N > 2) l2.ext(a, esign_lo, esign_hi, app_ext);
@@ -230,8 +230,12 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
     return p;
 }
 
-template <int BG, int ZC, int NCWG, bool FULL>
+// FULL : every layer of the base graph is active (n_layers == rows): no per-layer predicates, single mirror twin.
+// PLAIN: additionally no early termination and no soft output (the fixed-iteration throughput path): no
+//        per-thread `done` predicate, no extension-bit bookkeeping, no parity pass.
+template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN>
 __global__ __launch_bounds__(NCWG * ZC, (NCWG * ZC) / 256) void nrldpc_decode_z64_kernel(const DecArgs a) {
+    static_assert(!PLAIN || FULL, "PLAIN implies FULL");
     using G = Z64<BG, ZC, NCWG>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -311,18 +315,22 @@ __global__ __launch_bounds__(NCWG * ZC, (NCWG * ZC) / 256) void nrldpc_decode_z6
             if constexpr (LG::group_start(L) == L) { // L leads a barrier group
                 constexpr int GE = LG::group_last(L);
                 if constexpr (FULL) { // every layer active: no per-layer predicates at all
-                    if (!done) group_z64<BG, ZC, L, GE, FULL>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
+                    if constexpr (PLAIN) {
+                        if (active) group_z64<BG, ZC, L, GE, FULL, PLAIN>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
+                    } else {
+                        if (!done) group_z64<BG, ZC, L, GE, FULL, PLAIN>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
+                    }
                     __syncthreads();
                 } else {
                     const int nl = launder(a.n_layers);
                     if (L < nl) {
                         if (!done) {
                             if (GE < nl) {
-                                group_z64<BG, ZC, L, GE, FULL>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
+                                group_z64<BG, ZC, L, GE, FULL, PLAIN>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
                             } else { // the layer count cuts this group: its active layers one by one
                                 static_for<GE - L>([&](auto ic) {
                                     constexpr int LL = L + decltype(ic)::value;
-                                    if (LL < nl) group_z64<BG, ZC, LL, LL, FULL>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
+                                    if (LL < nl) group_z64<BG, ZC, LL, LL, FULL, PLAIN>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
                                 });
                             }
                         }
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(NCWG * ZC, (NCWG * ZC) / 256) void nrldpc_decode_z6
                 }
             }
         });
-        if (a.early_term) {
+        if constexpr (!PLAIN) if (a.early_term) {
             if (tid <= G::NCWG) flags[tid] = 0;
             __syncthreads();
             if (!done) {
@@ -361,9 +369,9 @@ __global__ __launch_bounds__(NCWG * ZC, (NCWG * ZC) / 256) void nrldpc_decode_z6
     }
 }
 
-template <int BG, int ZC, int NCWG, bool FULL> static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
+template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN> static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
     using G = Z64<BG, ZC, NCWG>;
-    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL>;
+    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL, PLAIN>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -374,7 +382,9 @@ template <int BG, int ZC, int NCWG, bool FULL> static hipError_t launch_z64f(con
 }
 
 template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
-    return a.n_layers == BGD<BG>::ROWS ? launch_z64f<BG, ZC, NCWG, true>(a, s) : launch_z64f<BG, ZC, NCWG, false>(a, s);
+    if (a.n_layers != BGD<BG>::ROWS) return launch_z64f<BG, ZC, NCWG, false, false>(a, s);
+    if (a.early_term || a.app) return launch_z64f<BG, ZC, NCWG, true, false>(a, s);
+    return launch_z64f<BG, ZC, NCWG, true, true>(a, s);
 }
 
 hipError_t launch_decode_z384(int bg, const DecArgs& a, hipStream_t stream) {

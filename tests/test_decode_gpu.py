@@ -56,6 +56,21 @@ def test_rate_pruned_layers(pkg, orc, bg, Z, nl, esn0):
     run_case(pkg, orc, rng, bg, Z, 3, esn0, 7, nl=nl, et=False)
 
 
+@pytest.mark.parametrize("bg", [1, 2])
+def test_z384_kernel_variants(pkg, orc, bg):
+    """The compile-time Z=384 kernel has three builds (plain fixed-iteration, full-H with early
+    termination / soft output, pruned layers); each against the oracle, with odd batch sizes so that a
+    workgroup holds one live and one dead codeword."""
+    rng = np.random.default_rng(384 + bg)
+    rows = BG_DIMS[bg][0]
+    for B in (1, 5):
+        run_case(pkg, orc, rng, bg, 384, B, 0.0, 6, nl=0, et=False, app=False)       # PLAIN
+        run_case(pkg, orc, rng, bg, 384, B, 0.0, 12, nl=0, et=True, app=False)       # FULL + early termination
+        run_case(pkg, orc, rng, bg, 384, B, 0.0, 5, nl=0, et=False, app=True)        # FULL + soft output
+        run_case(pkg, orc, rng, bg, 384, B, 2.0, 9, nl=rows - 1, et=True, app=True)  # pruned (cuts a barrier group)
+        run_case(pkg, orc, rng, bg, 384, B, 3.0, 7, nl=17, et=False, app=False)      # pruned, fixed iterations
+
+
 def test_per_iteration_soft_llrs(pkg, orc):
     """Soft a-posteriori LLRs after 1, 2, ..., 8 iterations (tolerance: none, values are k/scale exactly)."""
     rng = np.random.default_rng(77)
