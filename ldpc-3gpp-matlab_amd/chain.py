@@ -32,18 +32,21 @@ def _crc_table(poly, L):
 
 
 def crc_bits(bits, poly, L):
-    """CRC remainder (L bits, MSB first) of a 0/1 array."""
-    bits = np.asarray(bits, np.uint8).ravel()
-    pad = (-bits.size) % 8
+    """CRC remainder (L bits, MSB first) of a 0/1 array; a 2-D input [batch][n] gives [batch][L]."""
+    bits = np.asarray(bits, np.uint8)
+    single = bits.ndim == 1
+    bits = bits.reshape(1, -1) if single else bits
+    pad = (-bits.shape[1]) % 8
     if pad:  # leading zeros do not change a zero-initialised CRC
-        bits = np.concatenate([np.zeros(pad, np.uint8), bits])
-    data = np.packbits(bits)
+        bits = np.concatenate([np.zeros((bits.shape[0], pad), np.uint8), bits], axis=1)
+    data = np.packbits(bits, axis=1).astype(np.uint32)
     tab = _crc_table(poly, L)
-    mask = (1 << L) - 1
-    r = 0
-    for byte in data.tolist():
-        r = ((r << 8) & mask) ^ int(tab[((r >> (L - 8)) ^ byte) & 0xFF])
-    return np.array([(r >> (L - 1 - i)) & 1 for i in range(L)], np.uint8)
+    mask = np.uint32((1 << L) - 1)
+    r = np.zeros(bits.shape[0], np.uint32)
+    for k in range(data.shape[1]):  # byte-serial over the message, vectorised over the batch
+        r = ((r << np.uint32(8)) & mask) ^ tab[((r >> np.uint32(L - 8)) ^ data[:, k]) & np.uint32(0xFF)]
+    out = ((r[:, None] >> np.arange(L - 1, -1, -1, dtype=np.uint32)[None, :]) & np.uint32(1)).astype(np.uint8)
+    return out[0] if single else out
 
 
 # ---------------------------------------------------------------------------------------------

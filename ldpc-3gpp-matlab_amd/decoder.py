@@ -9,6 +9,9 @@ GPU as one batch through nrldpc_decode (the reference decodes them one by one, :
 algorithm is the build's layered normalised min-sum, not comm.LDPCDecoder's flooding sum-product
 (see DESIGN.md); `iterations` keeps the reference's meaning of 'MaximumIterationCount' and the
 parity-check early stop of :120 stays on.
+
+step_batch(g_tilde[B][G]) decodes B transport blocks at once (HARQ state is then kept per row); it
+returns (a_hat[B][A], ok[B]) where ok[b] is False exactly when the reference would return [].
 """
 import numpy as np
 
@@ -41,6 +44,7 @@ class NRLDPCDecoder(NRLDPC):
         self._prune = prune_layers
         self._codec = None
         self._codec_layers = None
+        self._nb = 1
         self.d_tilde_buffer = None
         self.b_hat_buffer = None
         self.code_block_CRC_passed = None
@@ -76,12 +80,18 @@ class NRLDPCDecoder(NRLDPC):
         object.__setattr__(self, "_locked", True)
         self.reset()
 
-    def reset(self):  # NRLDPCDecoder.m:343-356
+    def reset(self, rows=None):  # NRLDPCDecoder.m:343-356 (rows: only those transport blocks of a batch)
         if not self._locked:
             return
-        self.d_tilde_buffer = np.zeros((self.C, self.N_cb), np.float64)
-        self.b_hat_buffer = np.zeros(self.B, np.uint8)
-        self.code_block_CRC_passed = np.zeros(self.C, np.uint8)
+        nb = self._nb
+        if rows is None or self.d_tilde_buffer is None or self.d_tilde_buffer.shape[0] != nb:
+            self.d_tilde_buffer = np.zeros((nb, self.C, self.N_cb), np.float64)
+            self.b_hat_buffer = np.zeros((nb, self.B), np.uint8)
+            self.code_block_CRC_passed = np.zeros((nb, self.C), np.uint8)
+        else:
+            self.d_tilde_buffer[rows] = 0
+            self.b_hat_buffer[rows] = 0
+            self.code_block_CRC_passed[rows] = 0
         self._layers_seen = 4
 
     def release(self):
@@ -95,67 +105,87 @@ class NRLDPCDecoder(NRLDPC):
 
     def step(self, g_tilde):
         """g_tilde: G LLRs (positive = bit 0) -> a_hat: A bits, or an empty array on CRC failure."""
-        if not self._locked:
-            self._setup()
-        else:
-            self.validate()
         g_tilde = np.asarray(g_tilde, np.float64)
         if g_tilde.ndim == 2 and g_tilde.shape[1] == 1:
             g_tilde = g_tilde[:, 0]
         if g_tilde.ndim != 1 or g_tilde.size != self.G:
             raise NRLDPCError("g_tilde should be a column vector of length G.")
+        a_hat, ok = self.step_batch(g_tilde[None, :])
+        return a_hat[0] if ok[0] else np.zeros(0, np.uint8)
+
+    def step_batch(self, g_tilde):
+        g_tilde = np.asarray(g_tilde, np.float64)
+        if g_tilde.ndim != 2 or g_tilde.shape[1] != self.G:
+            raise NRLDPCError("g_tilde should be a column vector of length G.")
+        if not self._locked:
+            self._nb = g_tilde.shape[0]
+            self._setup()
+        else:
+            self.validate()
+            if g_tilde.shape[0] != self._nb:
+                self._nb = g_tilde.shape[0]
+                self.reset()
         d_tilde = self.rate_recover(g_tilde)
         c_hat = self.LDPC_coding(d_tilde)
         b_hat = self.code_block_segmentation(c_hat)
         return self.crc_calculation(b_hat)
 
-    # -- stages ----------------------------------------------------------------------------------
+    # -- stages (all on [B][...] arrays) -----------------------------------------------------------
     def rate_recover(self, g_tilde):
         """Stages 1-3: de-concatenate, de-interleave, soft-combining bit de-selection and the HARQ
         buffer (NRLDPCDecoder.m:143-242).  Filler positions are marked NaN as in the reference."""
+        g_tilde = np.asarray(g_tilde, np.float64)
+        single = g_tilde.ndim == 1
+        if single:
+            g_tilde = g_tilde[None]
+        nb = g_tilde.shape[0]
         N_, Z, K_, Kp, N_cb = self.N, self.Z_c, self.K, int(self.K_prime), self.N_cb
-        d = np.zeros((self.C, N_), np.float64)
+        d = np.zeros((nb, self.C, N_), np.float64)
+        rows = np.arange(nb)[:, None]
         for r, (off, dpos, fpos) in enumerate(chain.g_to_d_maps(self)):
-            if dpos.size:
-                np.add.at(d[r], dpos, g_tilde[off + fpos])  # repetition soft-combines (:229-231)
-        if self.I_HARQ != 0:  # :236-239
-            d[:, :N_cb] += self.d_tilde_buffer
-            self.d_tilde_buffer = d[:, :N_cb].copy()
-        d[:, max(Kp - 2 * Z, 0): K_ - 2 * Z] = np.nan  # :224
-        return d
+            if dpos.size:  # repetition soft-combines (:229-231); add.at keeps the reference's k order
+                np.add.at(d, (rows, r, dpos[None, :]), g_tilde[:, off + fpos])
+        if self.I_HARQ != 0 and self.d_tilde_buffer is not None and self.d_tilde_buffer.shape[0] == nb:  # :236-239
+            d[:, :, :N_cb] += self.d_tilde_buffer
+            self.d_tilde_buffer = d[:, :, :N_cb].copy()
+        d[:, :, max(Kp - 2 * Z, 0): K_ - 2 * Z] = np.nan  # :224
+        return d[0] if single else d
 
     def LDPC_coding(self, d_tilde):  # NRLDPCDecoder.m:245-268
         Z, K_ = self.Z_c, self.K
-        cw = np.concatenate([np.zeros((self.C, 2 * Z)), d_tilde], axis=1)  # :262
-        filler = np.isnan(cw[0, :K_])
+        nb, C_ = d_tilde.shape[0], self.C
+        cw = np.concatenate([np.zeros((nb, C_, 2 * Z)), d_tilde], axis=2)  # :262
+        filler = np.isnan(cw[0, 0, :K_])
         cw[np.isnan(cw)] = np.inf  # :264
         n_layers = 0
         if self._prune:
-            self._layers_seen = max(self._layers_seen, self.active_layers()) if self.I_HARQ else self.active_layers()
+            act = self.active_layers()
+            self._layers_seen = max(self._layers_seen, act) if self.I_HARQ else act
             n_layers = self._layers_seen
         want = n_layers if n_layers else (46 if self.BG == 1 else 42)
         if self._codec is None or self._codec_layers != want:
             self._make_codec(want)
-        hard, iters = self._codec.decode(cw.astype(np.float32), want_iters=True)  # :265
-        self.last_iterations = iters
-        c_hat = hard.astype(np.float64)
-        c_hat[:, filler] = np.nan  # :266
+        hard, iters = self._codec.decode(cw.astype(np.float32).reshape(nb * C_, -1), want_iters=True)  # :265
+        self.last_iterations = iters.reshape(nb, C_)
+        c_hat = hard.reshape(nb, C_, K_).astype(np.float64)
+        c_hat[:, :, filler] = np.nan  # :266
         return c_hat
 
     def code_block_segmentation(self, c_hat):  # NRLDPCDecoder.m:271-318
         C_, Kp, L = self.C, int(self.K_prime), self.code_block_L
+        nb = c_hat.shape[0]
         flags = self.CBGTI_flags
-        b_hat = self.b_hat_buffer.copy() if self.I_HARQ != 0 else np.zeros(self.B, np.uint8)
+        b_hat = self.b_hat_buffer.copy() if self.I_HARQ != 0 else np.zeros((nb, self.B), np.uint8)
         passed = self.code_block_CRC_passed.copy()
         s = 0
         for r in range(C_):
-            blk = c_hat[r, :Kp].astype(np.uint8)
-            failed = False
+            blk = c_hat[:, r, :Kp].astype(np.uint8)
+            failed = np.zeros(nb, bool)
             if C_ > 1:  # CB-CRC only when segmented (:298-301)
-                failed = bool(chain.crc_bits(blk, self.code_block_CRC_polynomial, L).any())
-            if not failed and flags[r] == 1:
-                b_hat[s: s + Kp - L] = blk[: Kp - L]
-                passed[r] = 1
+                failed = chain.crc_bits(blk, self.code_block_CRC_polynomial, L).any(axis=1)
+            good = ~failed & (flags[r] == 1)
+            b_hat[good, s: s + Kp - L] = blk[good, : Kp - L]
+            passed[good, r] = 1
             s += Kp - L
         if self.I_HARQ != 0:
             self.b_hat_buffer = b_hat.copy()
@@ -163,7 +193,6 @@ class NRLDPCDecoder(NRLDPC):
         return b_hat
 
     def crc_calculation(self, b_hat):  # NRLDPCDecoder.m:321-340
-        failed = bool(chain.crc_bits(b_hat, self.transport_block_CRC_polynomial, self.transport_block_L).any())
-        if failed or (self.code_block_CRC_passed == 0).any():
-            return np.zeros(0, np.uint8)
-        return b_hat[: self.A].copy()
+        failed = chain.crc_bits(b_hat, self.transport_block_CRC_polynomial, self.transport_block_L).any(axis=1)
+        ok = ~failed & (self.code_block_CRC_passed != 0).all(axis=1)
+        return b_hat[:, : self.A].copy(), ok

@@ -2,6 +2,8 @@
 
 step(a) runs the six TS 38.212 stages of NRLDPCEncoder.m:60-67; stage 3 (LDPC coding, :127-165)
 is the GPU encoder behind the C ABI (nrldpc_encode replaces step(obj.hLDPCEncoder, c) at :158).
+step_batch(a[B][A]) is the same chain for B transport blocks at once (all code blocks of all
+transport blocks in one launch) -- the reference encodes one block per step().
 """
 import numpy as np
 
@@ -36,45 +38,55 @@ class NRLDPCEncoder(NRLDPC):
 
     def step(self, a):
         """a: A information bits (0/1) -> g: G encoded bits (NRLDPCEncoder.m:60-67)."""
-        if self._codec is None:
-            self._setup()
-        else:
-            self.validate()
         a = np.asarray(a)
         if a.ndim == 2 and a.shape[1] == 1:
             a = a[:, 0]
         if a.ndim != 1 or a.size != self.A:
             raise NRLDPCError("a should be a column vector of length A.")
-        b = self.crc_calculation(a.astype(np.uint8))
-        c, filler = self.code_block_segmentation(b)
-        d = self.LDPC_coding(c)
-        return self.rate_match(d, filler)
+        return self.step_batch(a[None, :])[0]
 
-    # -- stages ----------------------------------------------------------------------------------
+    def step_batch(self, a):
+        """a: [B][A] bits -> g: [B][G] bits."""
+        if self._codec is None:
+            self._setup()
+        else:
+            self.validate()
+        a = np.asarray(a)
+        if a.ndim != 2 or a.shape[1] != self.A:
+            raise NRLDPCError("a should be a column vector of length A.")
+        b = self.crc_calculation(a.astype(np.uint8))
+        c = self.code_block_segmentation(b)
+        d = self.LDPC_coding(c)
+        return self.rate_match(d)
+
+    # -- stages (all on [B][...] arrays) -----------------------------------------------------------
     def crc_calculation(self, a):  # NRLDPCEncoder.m:70-89
         poly, L = self.transport_block_CRC_polynomial, self.transport_block_L
-        return np.concatenate([a, chain.crc_bits(a, poly, L)])
+        return np.concatenate([a, chain.crc_bits(a, poly, L)], axis=1)
 
-    def code_block_segmentation(self, b):  # NRLDPCEncoder.m:92-124
+    def code_block_segmentation(self, b):  # NRLDPCEncoder.m:92-124; filler bits (NaN there) are encoded as 0 (:153)
         C_, K_, Kp, L = self.C, self.K, int(self.K_prime), self.code_block_L
-        c = np.zeros((C_, K_), np.uint8)
+        c = np.zeros((b.shape[0], C_, K_), np.uint8)
         s = 0
         for r in range(C_):
-            c[r, : Kp - L] = b[s: s + Kp - L]
+            c[:, r, : Kp - L] = b[:, s: s + Kp - L]
             s += Kp - L
             if C_ > 1:
-                c[r, Kp - L: Kp] = chain.crc_bits(c[r, : Kp - L], self.code_block_CRC_polynomial, L)
-        filler = np.zeros(K_, bool)
-        filler[Kp:] = True  # <NULL> bits, NaN in the reference (:120-122); encoded as 0 (:153)
-        return c, filler
+                c[:, r, Kp - L: Kp] = chain.crc_bits(c[:, r, : Kp - L], self.code_block_CRC_polynomial, L)
+        return c
 
     def LDPC_coding(self, c):  # NRLDPCEncoder.m:127-165
-        cw = self._codec.encode(c)  # [C][N + 2Z], systematic
-        return cw[:, 2 * self.Z_c:]  # d = cw without the 2Z punctured columns (:149-163)
+        B, C_, K_ = c.shape
+        cw = self._codec.encode(c.reshape(B * C_, K_)).reshape(B, C_, -1)  # systematic [c; w]
+        return cw[:, :, 2 * self.Z_c:]  # d = cw without the 2Z punctured columns (:149-163)
 
-    def rate_match(self, d, filler):  # bit selection + interleaving + concatenation (:168-256)
-        g = np.zeros(self.G, np.uint8)
+    def rate_match(self, d, _filler=None):  # bit selection + interleaving + concatenation (:168-256)
+        d = np.asarray(d)
+        single = d.ndim == 2
+        if single:
+            d = d[None]
+        g = np.zeros((d.shape[0], self.G), np.uint8)
         for r, (off, dpos, fpos) in enumerate(chain.g_to_d_maps(self)):
             if dpos.size:
-                g[off + fpos] = d[r, dpos]
-        return g
+                g[:, off + fpos] = d[:, r, dpos]
+        return g[0] if single else g
