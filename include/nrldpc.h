@@ -87,6 +87,35 @@ int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t
 int nrldpc_encode(nrldpc_handle h, const uint8_t* info, int32_t batch, uint8_t* cw);
 int nrldpc_encode_dev(nrldpc_handle h, const uint8_t* d_info, int32_t batch, uint8_t* d_cw, void* stream);
 
+/* ---- stages either side of the core; stateless, current HIP device ---- */
+#define NRLDPC_MAX_C 160 /* code blocks per transport block */
+
+/* Parameters of one transport block as the reference derives them (NRLDPC.m:297-543). */
+typedef struct nrldpc_tb_params {
+    int32_t bg, Z;           /* BG, Z_c */
+    int32_t A, B, C;         /* payload, payload + TB CRC, code blocks */
+    int32_t K, K_prime, N;   /* per code block: K, K', N */
+    int32_t N_cb, k_0;       /* circular buffer length and start (NRLDPC.m:463-469, 510-543) */
+    int32_t Q_m, G;          /* bits per symbol, total rate-matched bits */
+    int32_t tb_crc_len;      /* 16 or 24 (CRC16 / CRC24A, NRLDPC.m:297-303) */
+    int32_t cb_crc_len;      /* 0 or 24 (CRC24B when C > 1, NRLDPC.m:347-353) */
+    int32_t E_r[NRLDPC_MAX_C]; /* NRLDPC.m:485-507 */
+} nrldpc_tb_params;
+
+/* Rate recovery: replaces code_block_concatenation + bit_interleaving + bit_selection (NRLDPCDecoder.m:143-242)
+ * and the 2Z-zero prefix / NaN->+inf of LDPC_coding (:262-264).  d_g_tilde: [n_tb][G] f32 LLRs.
+ * d_harq (nullable = I_HARQ 0): [n_tb][C][N_cb] f32 soft buffer, accumulated in place (:236-239).
+ * d_cw_llr: [n_tb*C][ncols*Z] of out_dtype (NRLDPC_LLR_F32 / _F16): the decoder core's input. */
+int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
+                            void* d_cw_llr, int32_t out_dtype, void* stream);
+
+/* CRC stages: replaces code_block_segmentation + crc_calculation of the decoder (NRLDPCDecoder.m:271-340).
+ * d_c_hat: [n_tb*C][K] hard bits from nrldpc_decode_dev.  d_b_hat: [n_tb][B] bytes (a_hat = first A of a row).
+ * d_ok: [n_tb], 0 where the reference returns [] (TB CRC or any CB CRC failed).  d_cb_pass (nullable):
+ * [n_tb][C] per-code-block CRC flags (code_block_CRC_passed, :95). */
+int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat,
+                         int32_t* d_ok, int32_t* d_cb_pass, void* stream);
+
 /* Kernel timing: when enabled, every *_dev / host call records HIP events around its kernel on the
  * launch stream; nrldpc_last_kernel_ms synchronises on the stop event and returns the duration. */
 int nrldpc_set_timing(nrldpc_handle h, int32_t enabled);

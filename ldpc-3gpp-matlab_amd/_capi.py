@@ -36,7 +36,28 @@ class Dims(C.Structure):
                 ("K", C.c_int32), ("N_cw", C.c_int32), ("n_layers", C.c_int32)]
 
 
-EXPORTS = ["nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
+MAX_C = 160
+
+
+class TbParams(C.Structure):
+    _fields_ = [("bg", C.c_int32), ("Z", C.c_int32), ("A", C.c_int32), ("B", C.c_int32), ("C", C.c_int32),
+                ("K", C.c_int32), ("K_prime", C.c_int32), ("N", C.c_int32), ("N_cb", C.c_int32), ("k_0", C.c_int32),
+                ("Q_m", C.c_int32), ("G", C.c_int32), ("tb_crc_len", C.c_int32), ("cb_crc_len", C.c_int32),
+                ("E_r", C.c_int32 * MAX_C)]
+
+
+def tb_params(p):
+    """nrldpc_tb_params from an NRLDPC parameter object (NRLDPC.m:297-543)."""
+    if p.C > MAX_C:
+        raise UnsupportedParameters("more than %d code blocks" % MAX_C)
+    t = TbParams(p.BG, p.Z_c, p.A, p.B, p.C, p.K, int(p.K_prime), p.N, p.N_cb, p.k_0, p.Q_m, p.G,
+                 p.transport_block_L, p.code_block_L)
+    for r, e in enumerate(p.E_r):
+        t.E_r[r] = e
+    return t
+
+
+EXPORTS = ["nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
            "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version"]
@@ -77,6 +98,8 @@ def load():
     L.nrldpc_decode_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.nrldpc_encode.argtypes = [vp, vp, i32, vp]
     L.nrldpc_encode_dev.argtypes = [vp, vp, i32, vp, vp]
+    L.nrldpc_rate_recover_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, i32, vp]
+    L.nrldpc_crc_check_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, vp, vp]
     L.nrldpc_set_timing.argtypes = [vp, i32]
     L.nrldpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nrldpc_set_index.argtypes = [i32]
@@ -180,6 +203,20 @@ class Codec:
         ms = C.c_float()
         check(self._lib.nrldpc_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+
+def rate_recover_dev(p, d_g_tilde, n_tb, d_harq, d_cw_llr, out_dtype=LLR_F32, stream=0):
+    """nrldpc_rate_recover_dev on raw device addresses (p: NRLDPC parameter object or TbParams)."""
+    t = p if isinstance(p, TbParams) else tb_params(p)
+    check(load().nrldpc_rate_recover_dev(C.byref(t), _ptr(d_g_tilde), int(n_tb), _ptr(d_harq), _ptr(d_cw_llr),
+                                         int(out_dtype), C.c_void_p(stream)))
+
+
+def crc_check_dev(p, d_c_hat, n_tb, d_b_hat, d_ok, d_cb_pass=None, stream=0):
+    """nrldpc_crc_check_dev on raw device addresses."""
+    t = p if isinstance(p, TbParams) else tb_params(p)
+    check(load().nrldpc_crc_check_dev(C.byref(t), _ptr(d_c_hat), int(n_tb), _ptr(d_b_hat), _ptr(d_ok),
+                                      _ptr(d_cb_pass), C.c_void_p(stream)))
 
 
 def set_index(Z):

@@ -311,6 +311,93 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     return NRLDPC_OK;
 }
 
+static uint32_t crc_poly_for(int len, bool code_block) {
+    // get_3gpp_crc_polynomial.m:3-14
+    if (len == 16) return 0x11021u;
+    return code_block ? 0x1800063u : 0x1864CFBu;
+}
+
+// x^n mod g as an L-bit register value
+static uint32_t xpow_mod(uint32_t poly, int L, long n) {
+    const uint32_t top = 1u << (L - 1), mask = (1u << L) - 1u;
+    uint32_t v = 1u; // x^0
+    for (long i = 0; i < n; ++i) {
+        const bool carry = v & top;
+        v = (v << 1) & mask;
+        if (carry) v ^= poly & mask;
+    }
+    return v;
+}
+
+static void make_crc_plan(nrldpc::CrcPlan* pl, uint32_t poly, int L, int len) {
+    pl->poly = poly; pl->L = L;
+    pl->chunk = (len + 63) / 64;
+    if (pl->chunk < 1) pl->chunk = 1;
+    for (int s = 0; s < 6; ++s) {
+        const long n = (long)pl->chunk << s;
+        uint32_t v = xpow_mod(poly, L, n); // x^n
+        const uint32_t top = 1u << (L - 1), mask = (1u << L) - 1u;
+        for (int b = 0; b < 24; ++b) {
+            pl->shiftmat[s][b] = (b < L) ? v : 0u; // x^(n+b)
+            const bool carry = v & top;
+            v = (v << 1) & mask;
+            if (carry) v ^= poly & mask;
+        }
+    }
+}
+
+static int check_tb_params(const nrldpc_tb_params* p) {
+    if (!p) return fail(NRLDPC_ERR_ARG, "null parameters");
+    if (p->C < 1 || p->C > NRLDPC_MAX_C) return fail(NRLDPC_ERR_UNSUPPORTED, "C out of range (1..160)");
+    if (nrldpc::set_index(p->Z) < 0 || (p->bg != 1 && p->bg != 2)) return fail(NRLDPC_ERR_UNSUPPORTED, "invalid BG / lifting size");
+    if (p->Q_m < 1 || p->N_cb < 1 || p->N_cb > p->N || p->K_prime > p->K) return fail(NRLDPC_ERR_UNSUPPORTED, "inconsistent block parameters");
+    return NRLDPC_OK;
+}
+
+int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
+                            void* d_cw_llr, int32_t out_dtype, void* stream) {
+    int rc = check_tb_params(p);
+    if (rc) return rc;
+    if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (n_tb == 0) return NRLDPC_OK;
+    if (!d_g_tilde || !d_cw_llr) return fail(NRLDPC_ERR_ARG, "null pointer");
+    if (out_dtype != NRLDPC_LLR_F32 && out_dtype != NRLDPC_LLR_F16) return fail(NRLDPC_ERR_ARG, "out_dtype must be f32 or f16");
+    nrldpc::RmArgs a;
+    a.g = d_g_tilde; a.harq = d_harq; a.out = d_cw_llr; a.out_f16 = out_dtype == NRLDPC_LLR_F16;
+    a.n_tb = n_tb; a.C = p->C; a.G = p->G; a.Z = p->Z; a.K = p->K; a.Kp = p->K_prime; a.N = p->N; a.N_cb = p->N_cb;
+    a.k0 = p->k_0; a.Qm = p->Q_m;
+    int off = 0;
+    for (int r = 0; r < p->C; ++r) {
+        if (p->E_r[r] < 0 || p->E_r[r] % p->Q_m) return fail(NRLDPC_ERR_UNSUPPORTED, "E_r must be a non-negative multiple of Q_m");
+        a.E[r] = p->E_r[r]; a.off[r] = off; off += p->E_r[r];
+    }
+    if (off != p->G) return fail(NRLDPC_ERR_ARG, "sum(E_r) must equal G");
+    hipError_t e = nrldpc::launch_rate_recover(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hipfail(e, "rate-recovery kernel launch");
+    return NRLDPC_OK;
+}
+
+int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat,
+                         int32_t* d_ok, int32_t* d_cb_pass, void* stream) {
+    int rc = check_tb_params(p);
+    if (rc) return rc;
+    if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (n_tb == 0) return NRLDPC_OK;
+    if (!d_c_hat || !d_b_hat || !d_ok) return fail(NRLDPC_ERR_ARG, "null pointer");
+    if ((p->tb_crc_len != 16 && p->tb_crc_len != 24) || (p->cb_crc_len != 0 && p->cb_crc_len != 24))
+        return fail(NRLDPC_ERR_UNSUPPORTED, "CRC lengths must be 16/24 (TB) and 0/24 (CB)");
+    if (p->B != p->A + p->tb_crc_len || p->C * (p->K_prime - p->cb_crc_len) != p->B)
+        return fail(NRLDPC_ERR_ARG, "B must equal A + L and C*(K' - L_cb)");
+    nrldpc::CrcArgs a;
+    a.c_hat = d_c_hat; a.b_hat = d_b_hat; a.ok = d_ok; a.cb_pass = d_cb_pass;
+    a.n_tb = n_tb; a.C = p->C; a.K = p->K; a.Kp = p->K_prime; a.Lcb = p->cb_crc_len; a.A = p->A; a.B = p->B;
+    make_crc_plan(&a.tb, crc_poly_for(p->tb_crc_len, false), p->tb_crc_len, p->B);
+    make_crc_plan(&a.cb, crc_poly_for(24, true), 24, p->K_prime);
+    hipError_t e = nrldpc::launch_crc_check(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hipfail(e, "CRC kernel launch");
+    return NRLDPC_OK;
+}
+
 int nrldpc_encode_dev(nrldpc_handle h, const uint8_t* d_info, int32_t batch, uint8_t* d_cw, void* stream) {
     if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");

@@ -38,5 +38,33 @@ struct EncArgs {
 
 hipError_t launch_encode(const EncArgs& a, hipStream_t stream);
 
+#define NRLDPC_MAX_C 160
+
+struct RmArgs {
+    const float* g;   // [n_tb][G] demodulator LLRs
+    float* harq;      // [n_tb][C][N_cb] soft buffer, accumulated in place; null when I_HARQ == 0
+    void* out;        // [n_tb*C][2Z+N] f32 or f16
+    int32_t out_f16;
+    int32_t n_tb, C, G, Z, K, Kp, N, N_cb, k0, Qm;
+    int32_t E[NRLDPC_MAX_C];   // E_r
+    int32_t off[NRLDPC_MAX_C]; // offset of code block r inside g_tilde
+};
+hipError_t launch_rate_recover(const RmArgs& a, hipStream_t stream);
+
+struct CrcPlan {
+    uint32_t poly;            // generator with the x^L term
+    int32_t L, chunk;         // CRC length, bits per lane (64*chunk >= message length)
+    uint32_t shiftmat[6][24]; // level s: column b = x^(b + chunk*2^s) mod g
+};
+struct CrcArgs {
+    const uint8_t* c_hat;     // [n_tb*C][K] decoded code blocks
+    uint8_t* b_hat;           // [n_tb][B]: payload + transport-block CRC; a_hat = first A bytes of a row
+    int32_t* ok;              // [n_tb]
+    int32_t* cb_pass;         // [n_tb][C] or null
+    int32_t n_tb, C, K, Kp, Lcb, A, B;
+    CrcPlan cb, tb;
+};
+hipError_t launch_crc_check(const CrcArgs& a, hipStream_t stream);
+
 } // namespace nrldpc
 #endif

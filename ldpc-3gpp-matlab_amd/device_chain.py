@@ -1,0 +1,83 @@
+"""Receive chain with every per-bit stage on the GPU: demodulator LLRs g_tilde in HBM -> rate recovery
+(nrldpc_rate_recover_dev, row N1) -> LDPC decode (nrldpc_decode_dev, the hot path) -> CRC stages
+(nrldpc_crc_check_dev, row N2) -> a_hat + ok flags.  The reference runs these as six interpreted stages
+per transport block (NRLDPCDecoder.m:133-140); here one transport-block batch is three kernel launches
+with no host loop and no PCIe traffic in between.  torch is used for device memory only.
+"""
+import numpy as np
+
+from ._capi import LLR_F16, LLR_F32, Codec, NRLDPCError, crc_check_dev, rate_recover_dev, tb_params
+from .decoder import default_alpha
+from .nrldpc import NRLDPC
+
+
+class DeviceDecodeChain:
+    """Batched NRLDPCDecoder.step on device tensors.  `params` is an NRLDPC parameter object (or any
+    NRLDPCDecoder); HARQ soft buffers live in HBM when I_HARQ is set."""
+
+    def __init__(self, params: NRLDPC, iterations=50, I_HARQ=0, alpha=None, llr_scale=0, prune_layers=True,
+                 llr_dtype=np.float16, device_id=0):
+        import torch
+        self.torch = torch
+        params.validate()
+        self.p = params
+        self.iterations, self.I_HARQ = int(iterations), int(I_HARQ)
+        self.alpha, self.llr_scale, self.prune = alpha, llr_scale, prune_layers
+        self.llr_dtype = np.dtype(llr_dtype)
+        self.dev = torch.device("cuda", device_id)
+        self.device_id = device_id
+        self._codec, self._codec_layers = None, None
+        self._layers_seen = 4
+        self.harq = None
+
+    def reset(self):
+        """reset(hDec): clears the incremental-redundancy buffer (NRLDPCDecoder.m:343-356)."""
+        if self.harq is not None:
+            self.harq.zero_()
+        self._layers_seen = 4
+
+    def close(self):
+        if self._codec is not None:
+            self._codec.close()
+            self._codec = None
+
+    def _codec_for(self, n_layers):
+        if self._codec is None or self._codec_layers != n_layers:
+            self.close()
+            a = self.alpha if self.alpha is not None else default_alpha(self.p.BG, n_layers)
+            self._codec = Codec(self.p.BG, self.p.Z_c, max_iter=self.iterations, n_layers=n_layers, early_term=True,
+                                alpha=a, llr_scale=self.llr_scale, llr_dtype=self.llr_dtype, device_id=self.device_id)
+            self._codec_layers = n_layers
+        return self._codec
+
+    def step(self, g_tilde):
+        """g_tilde: torch float32 tensor [n_tb][G] on the device (positive = bit 0).
+        Returns (a_hat uint8 [n_tb][A], ok bool [n_tb], iters int32 [n_tb][C]) as device tensors."""
+        torch, p = self.torch, self.p
+        if g_tilde.dim() != 2 or g_tilde.shape[1] != p.G or g_tilde.dtype != torch.float32 or not g_tilde.is_cuda:
+            raise NRLDPCError("g_tilde should be a float32 device tensor of shape [n_tb][G].")
+        g_tilde = g_tilde.contiguous()
+        n_tb, C_ = g_tilde.shape[0], p.C
+        t = tb_params(p)
+        stream = torch.cuda.current_stream().cuda_stream
+        ncwz = 2 * p.Z_c + p.N
+        if self.I_HARQ and (self.harq is None or self.harq.shape[0] != n_tb):
+            self.harq = torch.zeros((n_tb, C_, p.N_cb), dtype=torch.float32, device=self.dev)
+        tdt = torch.float16 if self.llr_dtype == np.float16 else torch.float32
+        cw_llr = torch.empty((n_tb * C_, ncwz), dtype=tdt, device=self.dev)
+        rate_recover_dev(t, g_tilde.data_ptr(), n_tb, self.harq.data_ptr() if self.I_HARQ else None,
+                         cw_llr.data_ptr(), LLR_F16 if tdt == torch.float16 else LLR_F32, stream)
+        rows = 46 if p.BG == 1 else 42
+        n_layers = rows
+        if self.prune:
+            act = p.active_layers()
+            self._layers_seen = max(self._layers_seen, act) if self.I_HARQ else act
+            n_layers = self._layers_seen
+        codec = self._codec_for(n_layers)
+        c_hat = torch.empty((n_tb * C_, p.K), dtype=torch.uint8, device=self.dev)
+        iters = torch.empty(n_tb * C_, dtype=torch.int32, device=self.dev)
+        codec.decode_dev(cw_llr.data_ptr(), n_tb * C_, c_hat.data_ptr(), iters.data_ptr(), None, stream)
+        b_hat = torch.empty((n_tb, p.B), dtype=torch.uint8, device=self.dev)
+        ok = torch.empty(n_tb, dtype=torch.int32, device=self.dev)
+        crc_check_dev(t, c_hat.data_ptr(), n_tb, b_hat.data_ptr(), ok.data_ptr(), None, stream)
+        return b_hat[:, : p.A], ok != 0, iters.view(n_tb, C_)

@@ -35,6 +35,9 @@ def lib():
         L.orc_decode_nmsq.argtypes = [i32, i32, i32, i32, i32, f32, i32, P, i32, P, P, P]
         L.orc_decode_bp_flood.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32]
         L.orc_set_threads.argtypes = [i32]
+        L.orc_rate_recover.argtypes = [i32] * 9 + [P, P, i32, P, P]
+        L.orc_crc.argtypes = [C.c_uint32, i32, P, i32]
+        L.orc_crc.restype = C.c_uint32
         _LIB = L
     return _LIB
 
@@ -95,3 +98,21 @@ def decode_bp_flood(bg, Z, llr, max_iter, n_layers=0, nthreads=0):
     rc = lib().orc_decode_bp_flood(bg, Z, n_layers, max_iter, _p(llr), B, _p(hard), _p(iters), nthreads)
     assert rc == 0, rc
     return hard, iters
+
+
+def rate_recover(Z, C_, K, K_prime, N, N_cb, k_0, Q_m, G, E_r, g_tilde, harq=None):
+    """Literal NRLDPCDecoder.m:143-242,262-264 in fp32; returns [n_tb*C][2Z+N] (harq updated in place)."""
+    g_tilde = np.ascontiguousarray(g_tilde, np.float32).reshape(-1, G)
+    n_tb = g_tilde.shape[0]
+    E = np.ascontiguousarray(E_r, np.int32)
+    out = np.zeros((n_tb * C_, 2 * Z + N), np.float32)
+    if harq is not None:
+        assert harq.dtype == np.float32 and harq.shape == (n_tb, C_, N_cb) and harq.flags.c_contiguous
+    rc = lib().orc_rate_recover(Z, C_, K, K_prime, N, N_cb, k_0, Q_m, G, _p(E), _p(g_tilde), n_tb, _p(harq), _p(out))
+    assert rc == 0
+    return out
+
+
+def crc(poly, L, bits):
+    bits = np.ascontiguousarray(bits, np.uint8)
+    return int(lib().orc_crc(poly, L, _p(bits), bits.size))
