@@ -98,6 +98,68 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
         });
     }
 
+    // ---- software-pipelined form (all layers active): an edge is "late" if its column is written by the
+    // barrier group in front of this layer's group (cyclically), otherwise "early": early edges may be read
+    // and folded into the min search BEFORE the barrier that separates the two groups.
+    static constexpr unsigned long long prev_written() {
+        using LG = LayerGroups<BG>;
+        return LG::group_mask((LG::group_index(L) + LG::ngroups() - 1) % LG::ngroups());
+    }
+    static constexpr bool is_late(int j) { return (prev_written() >> G::col(e0 + j)) & 1ull; }
+    float pm1, pm2;  // partial two-smallest search
+    uint32_t pS;     // partial sign parity
+
+    template <bool LATE> __device__ __forceinline__ void load_part(const char* lds, const uint32_t (&R)[ZC / 64]) {
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (LayerZ64::is_late(j) == LATE) {
+                constexpr int P = G::shift(e0 + j);
+                t[j] = *reinterpret_cast<const float*>(lds + R[P / 64] + G::col(e0 + j) * G::CS + 4 * (P % 64));
+            }
+        });
+    }
+    template <bool LATE> __device__ __forceinline__ void track_part(const DecState<BG>& st) {
+        if constexpr (!LATE) { pm1 = __builtin_inff(); pm2 = __builtin_inff(); pS = 0; }
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (LayerZ64::is_late(j) == LATE) {
+                constexpr int ce = ce0 + j;
+                const float tj = t[j] - byte_to_f32<ce & 3>(st.rm[ce >> 2]);
+                t[j] = tj;
+                const float aj = fabsf(tj);
+                pm2 = __builtin_amdgcn_fmed3f(aj, pm1, pm2);
+                pm1 = fminf(pm1, aj);
+                pS ^= fbits(tj);
+            }
+        });
+        if constexpr (!LATE && HAS_EXT) { // the extension bit is thread-private: always "early"
+            lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
+            const float al = fabsf(lam);
+            pm2 = __builtin_amdgcn_fmed3f(al, pm1, pm2);
+            pm1 = fminf(pm1, al);
+            pS ^= fbits(lam);
+        }
+    }
+    // pass 2 for all edges after both parts have been tracked
+    __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
+        m1 = pm1;
+        const uint32_t Sm = pS & 0x80000000u;
+        M1 = __uint_as_float(fbits(fminf(rintf(a.alpha * pm1), 127.0f)) | Sm);
+        M2 = __uint_as_float(fbits(fminf(rintf(a.alpha * pm2), 127.0f)) | Sm);
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int ce = ce0 + j;
+            constexpr int P = G::shift(e0 + j);
+            const float tj = t[j];
+            const float mag = (fabsf(tj) == m1) ? M2 : M1;
+            const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
+            f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
+            const float v = tj + r;
+            t[j] = v;
+            *reinterpret_cast<float*>(lds + R[P / 64] + G::col(e0 + j) * G::CS + 4 * (P % 64)) = v;
+        });
+    }
+
     __device__ __forceinline__ void update(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
         float mm1 = __builtin_inff(), mm2 = __builtin_inff();
         uint32_t S = 0;
@@ -210,6 +272,69 @@ __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uin
     }
 }
 
+// ---- software pipeline over barrier groups (FULL && PLAIN kernels) -------------------------------------
+// Group gi's layers; `early` = loads + min search over the edges that do not depend on the previous group.
+template <int BG, int ZC, int GI> struct GroupZ64 {
+    using LG = LayerGroups<BG>;
+    static constexpr int GS = LG::group_first(GI);
+    static constexpr int N = LG::group_last(GS) - GS + 1;
+    static_assert(N >= 1 && N <= 3, "group size");
+    LayerZ64<BG, ZC, GS, true> l0;
+    LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true> l1;
+    LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true> l2;
+
+    template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[ZC / 64]) {
+        l0.template load_part<LATE>(lds, R);
+        if constexpr (N > 1) l1.template load_part<LATE>(lds, R);
+        if constexpr (N > 2) l2.template load_part<LATE>(lds, R);
+    }
+    template <bool LATE> __device__ __forceinline__ void track(const DecState<BG>& st) {
+        l0.template track_part<LATE>(st);
+        if constexpr (N > 1) l1.template track_part<LATE>(st);
+        if constexpr (N > 2) l2.template track_part<LATE>(st);
+    }
+    __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
+        l0.finish(st, lds, R, a);
+        if constexpr (N > 1) l1.finish(st, lds, R, a);
+        if constexpr (N > 2) l2.finish(st, lds, R, a);
+    }
+    __device__ __forceinline__ void twins(char* lds, uint32_t RA, uint32_t RB, int w) const {
+        dispatch_w<0, ZC / 64>(w, [&](auto wc) {
+            constexpr int WV = decltype(wc)::value;
+            l0.template twins<WV>(lds, RA, RB);
+            if constexpr (N > 1) l1.template twins<WV>(lds, RA, RB);
+            if constexpr (N > 2) l2.template twins<WV>(lds, RA, RB);
+        });
+    }
+};
+
+// One iteration: group GI arrives with its early part done; barrier; late part; pass 2; the NEXT group's early
+// part is started before this group's pass 2 so that its LDS latency and min search overlap the barrier wait.
+// Returns (through `next0`) group 0 with its early part done for the following iteration.
+template <int BG, int ZC, int GI>
+__device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI>& cur, GroupZ64<BG, ZC, 0>& next0, DecState<BG>& st,
+                                             char* lds, const uint32_t (&R)[ZC / 64], uint32_t RA, uint32_t RB,
+                                             int w, const DecArgs& a) {
+    constexpr int NG = LayerGroups<BG>::ngroups();
+    __syncthreads(); // ends group GI-1 (for GI == 0: the previous iteration / the prologue)
+    cur.template loads<true>(lds, R);
+    if constexpr (GI + 1 < NG) {
+        GroupZ64<BG, ZC, GI + 1> nxt;
+        nxt.template loads<false>(lds, R); // columns untouched by group GI: safe before its writes
+        cur.template track<true>(st);
+        cur.finish(st, lds, R, a);
+        cur.twins(lds, RA, RB, w);
+        nxt.template track<false>(st);
+        pipeline_z64<BG, ZC, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a);
+    } else {
+        next0.template loads<false>(lds, R);
+        cur.template track<true>(st);
+        cur.finish(st, lds, R, a);
+        cur.twins(lds, RA, RB, w);
+        next0.template track<false>(st);
+    }
+}
+
 template <int BG, int ZC, int L>
 __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R)[ZC / 64], uint32_t esign_lo,
                                                    uint32_t esign_hi) {
@@ -305,9 +430,26 @@ __global__ __launch_bounds__(NCWG * ZC, (NCWG * ZC) / 256) void nrldpc_decode_z6
     }
     __syncthreads();
 
+    if constexpr (PLAIN) {
+        // fixed-iteration path: barrier groups software-pipelined (see pipeline_z64)
+        if (active) {
+            GroupZ64<BG, ZC, 0> g0;
+            g0.template loads<false>(lds, R);
+            g0.template track<false>(st);
+            for (int it = 1; it <= a.max_iter; ++it) {
+                GroupZ64<BG, ZC, 0> nx;
+                pipeline_z64<BG, ZC, 0>(g0, nx, st, lds, R, RA, RB, w, a);
+                g0 = nx;
+            }
+        } else {
+            for (int it = 1; it <= a.max_iter; ++it)
+                for (int g = 0; g < LayerGroups<BG>::ngroups(); ++g) __syncthreads();
+        }
+        __syncthreads();
+    }
     bool done = !active;
     int my_iters = a.max_iter;
-    for (int it = 1; it <= a.max_iter; ++it) {
+    if constexpr (!PLAIN) for (int it = 1; it <= a.max_iter; ++it) {
         if (!done) { esign_lo = 0; esign_hi = 0; }
         static_for<G::ROWS>([&](auto lc) {
             constexpr int L = decltype(lc)::value;

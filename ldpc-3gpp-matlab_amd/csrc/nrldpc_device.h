@@ -49,22 +49,38 @@ template <int BG> struct LayerGroups {
             if (G::col(e) < G::NC) m |= 1ull << G::col(e);
         return m;
     }
-    // first layer of the group that contains layer L
-    static constexpr int group_start(int L) {
-        int start = 0;
+    struct Tab {
+        int gstart[G::ROWS];              // first layer of the group containing layer L
+        int glast[G::ROWS];               // last layer of that group
+        int gindex[G::ROWS];              // group number of layer L
+        int gfirst[G::ROWS];              // first layer of group number gi
+        unsigned long long gmask[G::ROWS]; // core columns written by group number gi
+        int n;                            // number of groups (all layers active)
+    };
+    static constexpr Tab make() {
+        Tab t{};
+        int start = 0, gi = -1;
         unsigned long long acc = 0;
-        for (int l = 0; l <= L; ++l) {
+        for (int l = 0; l < G::ROWS; ++l) {
             const unsigned long long m = colmask(l);
-            if (acc & m) { start = l; acc = m; } else acc |= m;
+            if (l == 0 || (acc & m)) { start = l; acc = m; ++gi; t.gfirst[gi] = l; t.gmask[gi] = 0; } else acc |= m;
+            t.gstart[l] = start;
+            t.gindex[l] = gi;
+            t.gmask[gi] |= m;
         }
-        return start;
+        t.n = gi + 1;
+        for (int l = G::ROWS - 1; l >= 0; --l)
+            t.glast[l] = (l + 1 < G::ROWS && t.gstart[l + 1] == t.gstart[l]) ? t.glast[l + 1] : l;
+        return t;
     }
-    static constexpr bool group_end(int L) { return L + 1 >= G::ROWS || group_start(L + 1) == L + 1; }
-    static constexpr int group_last(int L) {
-        int l = L;
-        while (!group_end(l)) ++l;
-        return l;
-    }
+    static constexpr Tab T = make();
+    static constexpr int group_start(int L) { return T.gstart[L]; }
+    static constexpr bool group_end(int L) { return T.glast[L] == L; }
+    static constexpr int group_last(int L) { return T.glast[L]; }
+    static constexpr int group_index(int L) { return T.gindex[L]; }
+    static constexpr int ngroups() { return T.n; }
+    static constexpr int group_first(int gi) { return T.gfirst[gi]; }
+    static constexpr unsigned long long group_mask(int gi) { return T.gmask[gi]; }
 };
 
 template <class F, int... I>
