@@ -223,9 +223,13 @@ __global__ __launch_bounds__(768) void nrldpc_decode_kernel(const DecArgs a, con
 
 template <int BG, int DT> static hipError_t launch_t(const DecArgs& a, int grid, int threads, size_t lds, hipStream_t s) {
     auto k = nrldpc_decode_kernel<BG, DT>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_set[64] = {}; // per device: raising the dynamic-LDS limit is a slow host call, do it once
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a, a.rot);
     return hipGetLastError();

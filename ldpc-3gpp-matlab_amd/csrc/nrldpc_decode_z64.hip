@@ -516,8 +516,14 @@ template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN> static hipError_t lau
     auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL, PLAIN>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static bool attr_set[64] = {}; // per device: raising the dynamic-LDS limit is a slow host call, do it once
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
     const int grid = (a.batch + G::NCWG - 1) / G::NCWG;
     hipLaunchKernelGGL(k, dim3(grid), dim3(G::NCWG * ZC), lds, s, a);
     return hipGetLastError();

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Throughput of every BASELINE.json configuration on one MI355X (kernel time from HIP events inside the
+library, LLRs resident in HBM as fp16).  Writes gpurun_out/bench_configs.json.  Not the driver's bench
+(bench.py is); this is the per-configuration evidence cited in DESIGN.md."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("ldpc-3gpp-matlab_amd")
+DIMS = {1: (46, 68, 22), 2: (42, 52, 10)}
+ALL_Z = sorted(a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384)
+
+
+def synth(codec, bg, Z, B, E, esn0, seed):
+    rows, cols, kb = DIMS[bg]
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    info = torch.randint(0, 2, (B, kb * Z), generator=g, device="cuda", dtype=torch.uint8)
+    cw = torch.empty((B, cols * Z), device="cuda", dtype=torch.uint8)
+    codec.encode_dev(info.data_ptr(), B, cw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    mu = 2.0 * 10 ** (esn0 / 10)
+    llr = (1 - 2 * cw.float()) * mu + (2 * mu) ** 0.5 * torch.randn((B, cols * Z), generator=g, device="cuda")
+    llr[:, : 2 * Z] = 0
+    llr[:, 2 * Z + E:] = 0
+    return info, llr.half().contiguous()
+
+
+def run(name, bg, Z, B, E, nl, iters, et, esn0, reps=5):
+    rows, cols, kb = DIMS[bg]
+    codec = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, alpha=pkg.default_alpha(bg, nl or rows),
+                      llr_dtype=np.float16)
+    info, llr = synth(codec, bg, Z, B, E, esn0, 1234)
+    hard = torch.empty((B, kb * Z), device="cuda", dtype=torch.uint8)
+    its = torch.empty(B, device="cuda", dtype=torch.int32)
+    s = torch.cuda.current_stream().cuda_stream
+    codec.set_timing(True)
+    ms = []
+    for i in range(reps + 1):
+        codec.decode_dev(llr.data_ptr(), B, hard.data_ptr(), its.data_ptr(), None, s)
+        t = codec.last_kernel_ms()
+        if i:
+            ms.append(t)
+    codec.close()
+    t = float(np.median(ms))
+    rec = {"config": name, "bg": bg, "Z": Z, "batch": B, "E": E, "n_layers": nl or rows, "max_iter": iters,
+           "early_term": bool(et), "EsN0_dB": esn0, "kernel_ms": t, "info_Gbit_s": B * kb * Z / t / 1e6,
+           "bler": float((hard != info).any(1).float().mean()), "mean_iters": float(its.float().mean())}
+    print(rec, flush=True)
+    return rec
+
+
+def mixed(B=8192, iters=25):
+    rng = np.random.default_rng(4)
+    draws = [(int(rng.integers(1, 3)), int(rng.choice(ALL_Z))) for _ in range(B)]
+    buckets = {}
+    for key in draws:
+        buckets[key] = buckets.get(key, 0) + 1
+    work = []
+    for (bg, Z), n in sorted(buckets.items()):
+        rows, cols, kb = DIMS[bg]
+        codec = pkg.Codec(bg, Z, max_iter=iters, early_term=True, alpha=0.625, llr_dtype=np.float16)
+        info, llr = synth(codec, bg, Z, n, cols * Z, 3.0, Z)
+        hard = torch.empty((n, kb * Z), device="cuda", dtype=torch.uint8)
+        work.append((codec, llr, hard, n, kb * Z))
+    import time
+    streams = [torch.cuda.Stream() for _ in range(8)]  # small buckets overlap on separate HIP streams
+    best = None
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i, (codec, llr, hard, n, K) in enumerate(work):
+            codec.decode_dev(llr.data_ptr(), n, hard.data_ptr(), None, None, streams[i % 8].cuda_stream)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) * 1e3
+        best = t if best is None else min(best, t)
+    bits = sum(n * K for _, _, _, n, K in work)
+    for w in work:
+        w[0].close()
+    rec = {"config": "cfg4 mixed BG1/BG2, Z in {2..384}, batch 8192, one launch per (BG,Z) bucket on 8 HIP streams", "buckets": len(work),
+           "wall_ms_all_launches": best, "info_Gbit_s": bits / best / 1e6, "info_bits": bits}
+    print(rec, flush=True)
+    return rec
+
+
+def main():
+    out = []
+    out.append(run("cfg2 BG1 Z=384 R=1/3 25it fixed, batch 4096 (headline)", 1, 384, 4096, 25344, 0, 25, 0, -0.5))
+    out.append(run("cfg2 with parity-check early stop (reference semantics)", 1, 384, 4096, 25344, 0, 25, 1, -0.5))
+    for R, E, nl, esn0 in (("1/5", 19120, 42, -3.0), ("1/4", 15296, 32, -2.0), ("1/3", 11472, 22, -0.5), ("2/5", 9560, 17, 0.5),
+                           ("1/2", 7648, 12, 2.0), ("3/5", 6374, 9, 3.2), ("2/3", 5736, 7, 4.5)):
+        out.append(run("cfg3 BG2 Z=384 R=%s 25it fixed, batch 4096" % R, 2, 384, 4096, E, nl, 25, 0, esn0))
+        out.append(run("cfg3 BG2 Z=384 R=%s early stop, batch 4096" % R, 2, 384, 4096, E, nl, 25, 1, esn0))
+    out.append(mixed())
+    out.append(run("cfg5 BG1 Z=384 R=8/9 early stop, 8192 codewords (one GPU's shard of 65536)", 1, 384, 8192, 9478, 5, 25, 1, 7.5))
+    out.append(run("cfg5 worst case: no early stop", 1, 384, 8192, 9478, 5, 25, 0, 7.5))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
