@@ -359,7 +359,7 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
 // PLAIN: additionally no early termination and no soft output (the fixed-iteration throughput path): no
 //        per-thread `done` predicate, no extension-bit bookkeeping, no parity pass.
 template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN>
-__global__ __launch_bounds__(NCWG * ZC, (NCWG * ZC) / 256) void nrldpc_decode_z64_kernel(const DecArgs a) {
+__global__ __launch_bounds__(NCWG * ZC, BG == 2 ? 6 : 3) void nrldpc_decode_z64_kernel(const DecArgs a) {
     static_assert(!PLAIN || FULL, "PLAIN implies FULL");
     using G = Z64<BG, ZC, NCWG>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
