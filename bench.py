@@ -173,8 +173,9 @@ def main():
                        "sharding": "codeword batches per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "nrldpc_decode_kernel<1,f16>", "kernel_ms": kernel_ms,
+                         "kernel": "nrldpc::nrldpc_decode_z64_kernel<1, 384, 2, true, true>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_codeword": ALG_BYTES_PER_CW,
+                         "hbm_achieved_GBs_from_traffic": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "note": "algorithmic = streaming-model bytes (SURVEY 8d, s=2); codewords stay in "
                                  "LDS/VGPRs for all iterations so frac may exceed 1; compulsory HBM I/O is "
                                  "%d B/codeword" % (N_CW * S_BYTES + K)},
