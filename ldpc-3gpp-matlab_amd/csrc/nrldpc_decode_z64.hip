@@ -146,12 +146,17 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
         const uint32_t Sm = pS & 0x80000000u;
         M1 = __uint_as_float(fbits(fminf(rintf(a.alpha * pm1), 127.0f)) | Sm);
         M2 = __uint_as_float(fbits(fminf(rintf(a.alpha * pm2), 127.0f)) | Sm);
+        bool ismin[ncore]; // all compares first: keeps v_cmp -> v_cndmask hazard slots filled with useful work
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            ismin[j] = fabsf(t[j]) == m1;
+        });
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int ce = ce0 + j;
             constexpr int P = G::shift(e0 + j);
             const float tj = t[j];
-            const float mag = (fabsf(tj) == m1) ? M2 : M1;
+            const float mag = ismin[j] ? M2 : M1;
             const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
             f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
             const float v = tj + r;
@@ -213,14 +218,13 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
             constexpr int off = G::col(e0 + j) * G::CS + 4 * (P % 64);
             if constexpr ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
                           (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV)) {
-                // opaque copy: stops SimplifyCFG sinking the per-wave stores into one store that indexes t[]
-                // dynamically (which would push t[] to scratch)
-                float v = t[j];
-                asm volatile("" : "+v"(v));
                 if constexpr (G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV)
-                    *reinterpret_cast<float*>(lds + RA + off) = v;
+                    *reinterpret_cast<float*>(lds + RA + off) = t[j];
                 if constexpr (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV)
-                    *reinterpret_cast<float*>(lds + RB + off) = v;
+                    *reinterpret_cast<float*>(lds + RB + off) = t[j];
+                // A unique (empty) asm per store: without it SimplifyCFG sinks the six per-wave store
+                // sequences into one store that indexes t[] dynamically, which pushes t[] to scratch.
+                asm volatile("; twin L%c0 e%c1 w%c2" ::"i"(L), "i"(j), "i"(WV));
             }
         });
     }
