@@ -118,8 +118,17 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
             }
         });
     }
-    template <bool LATE> __device__ __forceinline__ void track_part(const DecState<BG>& st) {
-        if constexpr (!LATE) { pm1 = __builtin_inff(); pm2 = __builtin_inff(); pS = 0; }
+    // number of edges of the requested part among edges 0..j-1 (compile time): pairs of sign words are folded
+    // into the parity with one three-input xor (v_bitop3_b32 0x96) instead of two v_xor
+    template <bool LATE> static constexpr int part_count_before(int j) {
+        int n = 0;
+        for (int i = 0; i < j; ++i) n += (is_late(i) == LATE);
+        return n;
+    }
+    template <bool LATE> __device__ __forceinline__ void track_part(const DecState<BG>& st, float cap) {
+        // cap = 127.49/alpha: the search starts from it, so alpha*m never exceeds 127 and needs no clamp
+        if constexpr (!LATE) { pm1 = cap; pm2 = cap; pS = 0; }
+        uint32_t pend = 0;
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (LayerZ64::is_late(j) == LATE) {
@@ -129,23 +138,28 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
                 const float aj = fabsf(tj);
                 pm2 = __builtin_amdgcn_fmed3f(aj, pm1, pm2);
                 pm1 = fminf(pm1, aj);
-                pS ^= fbits(tj);
+                if constexpr (LayerZ64::template part_count_before<LATE>(j) % 2 == 0) pend = fbits(tj);
+                else pS = __builtin_amdgcn_bitop3_b32(pS, pend, fbits(tj), 0x96);
             }
         });
+        constexpr int npart = part_count_before<LATE>(ncore);
         if constexpr (!LATE && HAS_EXT) { // the extension bit is thread-private: always "early"
             lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
             const float al = fabsf(lam);
             pm2 = __builtin_amdgcn_fmed3f(al, pm1, pm2);
             pm1 = fminf(pm1, al);
-            pS ^= fbits(lam);
+            if constexpr (npart % 2 == 1) pS = __builtin_amdgcn_bitop3_b32(pS, pend, fbits(lam), 0x96);
+            else pS ^= fbits(lam);
+        } else {
+            if constexpr (npart % 2 == 1) pS ^= pend;
         }
     }
     // pass 2 for all edges after both parts have been tracked
     __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
         m1 = pm1;
-        const uint32_t Sm = pS & 0x80000000u;
-        M1 = __uint_as_float(fbits(fminf(rintf(a.alpha * pm1), 127.0f)) | Sm);
-        M2 = __uint_as_float(fbits(fminf(rintf(a.alpha * pm2), 127.0f)) | Sm);
+        // magnitudes carrying the row's sign parity: M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
+        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(rintf(a.alpha * pm1)), pS, 0x80000000u, 0xF8));
+        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(rintf(a.alpha * pm2)), pS, 0x80000000u, 0xF8));
         bool ismin[ncore]; // all compares first: keeps v_cmp -> v_cndmask hazard slots filled with useful work
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -292,10 +306,10 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
         if constexpr (N > 1) l1.template load_part<LATE>(lds, R);
         if constexpr (N > 2) l2.template load_part<LATE>(lds, R);
     }
-    template <bool LATE> __device__ __forceinline__ void track(const DecState<BG>& st) {
-        l0.template track_part<LATE>(st);
-        if constexpr (N > 1) l1.template track_part<LATE>(st);
-        if constexpr (N > 2) l2.template track_part<LATE>(st);
+    template <bool LATE> __device__ __forceinline__ void track(const DecState<BG>& st, float cap) {
+        l0.template track_part<LATE>(st, cap);
+        if constexpr (N > 1) l1.template track_part<LATE>(st, cap);
+        if constexpr (N > 2) l2.template track_part<LATE>(st, cap);
     }
     __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
         l0.finish(st, lds, R, a);
@@ -318,24 +332,24 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
 template <int BG, int ZC, int GI>
 __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI>& cur, GroupZ64<BG, ZC, 0>& next0, DecState<BG>& st,
                                              char* lds, const uint32_t (&R)[ZC / 64], uint32_t RA, uint32_t RB,
-                                             int w, const DecArgs& a) {
+                                             int w, const DecArgs& a, float cap) {
     constexpr int NG = LayerGroups<BG>::ngroups();
     __syncthreads(); // ends group GI-1 (for GI == 0: the previous iteration / the prologue)
     cur.template loads<true>(lds, R);
     if constexpr (GI + 1 < NG) {
         GroupZ64<BG, ZC, GI + 1> nxt;
         nxt.template loads<false>(lds, R); // columns untouched by group GI: safe before its writes
-        cur.template track<true>(st);
+        cur.template track<true>(st, cap);
         cur.finish(st, lds, R, a);
         cur.twins(lds, RA, RB, w);
-        nxt.template track<false>(st);
-        pipeline_z64<BG, ZC, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a);
+        nxt.template track<false>(st, cap);
+        pipeline_z64<BG, ZC, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap);
     } else {
         next0.template loads<false>(lds, R);
-        cur.template track<true>(st);
+        cur.template track<true>(st, cap);
         cur.finish(st, lds, R, a);
         cur.twins(lds, RA, RB, w);
-        next0.template track<false>(st);
+        next0.template track<false>(st, cap);
     }
 }
 
@@ -437,12 +451,13 @@ __global__ __launch_bounds__(NCWG * ZC, BG == 2 ? 6 : 3) void nrldpc_decode_z64_
     if constexpr (PLAIN) {
         // fixed-iteration path: barrier groups software-pipelined (see pipeline_z64)
         if (active) {
+            const float cap = 127.49f / a.alpha; // see track_part
             GroupZ64<BG, ZC, 0> g0;
             g0.template loads<false>(lds, R);
-            g0.template track<false>(st);
+            g0.template track<false>(st, cap);
             for (int it = 1; it <= a.max_iter; ++it) {
                 GroupZ64<BG, ZC, 0> nx;
-                pipeline_z64<BG, ZC, 0>(g0, nx, st, lds, R, RA, RB, w, a);
+                pipeline_z64<BG, ZC, 0>(g0, nx, st, lds, R, RA, RB, w, a, cap);
                 g0 = nx;
             }
         } else {
