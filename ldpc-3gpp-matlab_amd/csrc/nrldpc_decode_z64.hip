@@ -181,7 +181,7 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
 
     __device__ __forceinline__ void update(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
         float mm1 = __builtin_inff(), mm2 = __builtin_inff();
-        uint32_t S = 0;
+        uint32_t S = 0, pend = 0;
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int ce = ce0 + j;
@@ -190,7 +190,8 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
             const float aj = fabsf(tj);
             mm2 = __builtin_amdgcn_fmed3f(aj, mm1, mm2);
             mm1 = fminf(mm1, aj);
-            S ^= fbits(tj);
+            if constexpr (j % 2 == 0) pend = fbits(tj);
+            else S = __builtin_amdgcn_bitop3_b32(S, pend, fbits(tj), 0x96); // three-input xor
         });
         lam = 0.0f;
         if constexpr (HAS_EXT) {
@@ -198,13 +199,16 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
             const float al = fabsf(lam);
             mm2 = __builtin_amdgcn_fmed3f(al, mm1, mm2);
             mm1 = fminf(mm1, al);
-            S ^= fbits(lam);
+            if constexpr (ncore % 2 == 1) S = __builtin_amdgcn_bitop3_b32(S, pend, fbits(lam), 0x96);
+            else S ^= fbits(lam);
+        } else {
+            if constexpr (ncore % 2 == 1) S ^= pend;
         }
         m1 = mm1;
-        // magnitudes carrying the row's sign parity; the edge's own sign is xor-ed in per edge
-        const uint32_t Sm = S & 0x80000000u;
-        M1 = __uint_as_float(fbits(fminf(rintf(a.alpha * mm1), 127.0f)) | Sm);
-        M2 = __uint_as_float(fbits(fminf(rintf(a.alpha * mm2), 127.0f)) | Sm);
+        // magnitudes carrying the row's sign parity (M | (S & signbit), one v_bitop3_b32); the edge's own sign is
+        // xor-ed in per edge
+        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(fminf(rintf(a.alpha * mm1), 127.0f)), S, 0x80000000u, 0xF8));
+        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(fminf(rintf(a.alpha * mm2), 127.0f)), S, 0x80000000u, 0xF8));
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int ce = ce0 + j;
