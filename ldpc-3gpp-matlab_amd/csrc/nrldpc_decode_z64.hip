@@ -301,9 +301,10 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
     static constexpr int GS = LG::group_first(GI);
     static constexpr int N = LG::group_last(GS) - GS + 1;
     static_assert(N >= 1 && N <= 3, "group size");
+    struct NoLayer {}; // absent second / third layer: no storage, so copying a group copies only live state
     LayerZ64<BG, ZC, GS, true> l0;
-    LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true> l1;
-    LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true> l2;
+    std::conditional_t<(N > 1), LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true>, NoLayer> l1;
+    std::conditional_t<(N > 2), LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true>, NoLayer> l2;
 
     template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[ZC / 64]) {
         l0.template load_part<LATE>(lds, R);
