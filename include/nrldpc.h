@@ -116,6 +116,14 @@ int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, i
 int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat,
                          int32_t* d_ok, int32_t* d_cb_pass, void* stream);
 
+/* Transmit-side counterparts (vector generation for the Monte-Carlo harness, plot_BLER_vs_SNR.m:129):
+ * nrldpc_crc_attach_dev replaces crc_calculation + code_block_segmentation of the encoder
+ * (NRLDPCEncoder.m:70-124): d_a [n_tb][A] bits -> d_c [n_tb*C][K] code blocks (fillers 0), ready for
+ * nrldpc_encode_dev.  nrldpc_rate_match_dev replaces bit_selection + bit_interleaving +
+ * code_block_concatenation (NRLDPCEncoder.m:168-256): d_cw [n_tb*C][ncols*Z] -> d_g [n_tb][G]. */
+int nrldpc_crc_attach_dev(const nrldpc_tb_params* p, const uint8_t* d_a, int32_t n_tb, uint8_t* d_c, void* stream);
+int nrldpc_rate_match_dev(const nrldpc_tb_params* p, const uint8_t* d_cw, int32_t n_tb, uint8_t* d_g, void* stream);
+
 /* Kernel timing: when enabled, every *_dev / host call records HIP events around its kernel on the
  * launch stream; nrldpc_last_kernel_ms synchronises on the stop event and returns the duration. */
 int nrldpc_set_timing(nrldpc_handle h, int32_t enabled);

@@ -57,7 +57,7 @@ def tb_params(p):
     return t
 
 
-EXPORTS = ["nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
+EXPORTS = ["nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
            "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version"]
@@ -100,6 +100,8 @@ def load():
     L.nrldpc_encode_dev.argtypes = [vp, vp, i32, vp, vp]
     L.nrldpc_rate_recover_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, i32, vp]
     L.nrldpc_crc_check_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, vp, vp]
+    L.nrldpc_crc_attach_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp]
+    L.nrldpc_rate_match_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp]
     L.nrldpc_set_timing.argtypes = [vp, i32]
     L.nrldpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nrldpc_set_index.argtypes = [i32]
@@ -217,6 +219,16 @@ def crc_check_dev(p, d_c_hat, n_tb, d_b_hat, d_ok, d_cb_pass=None, stream=0):
     t = p if isinstance(p, TbParams) else tb_params(p)
     check(load().nrldpc_crc_check_dev(C.byref(t), _ptr(d_c_hat), int(n_tb), _ptr(d_b_hat), _ptr(d_ok),
                                       _ptr(d_cb_pass), C.c_void_p(stream)))
+
+
+def crc_attach_dev(p, d_a, n_tb, d_c, stream=0):
+    t = p if isinstance(p, TbParams) else tb_params(p)
+    check(load().nrldpc_crc_attach_dev(C.byref(t), _ptr(d_a), int(n_tb), _ptr(d_c), C.c_void_p(stream)))
+
+
+def rate_match_dev(p, d_cw, n_tb, d_g, stream=0):
+    t = p if isinstance(p, TbParams) else tb_params(p)
+    check(load().nrldpc_rate_match_dev(C.byref(t), _ptr(d_cw), int(n_tb), _ptr(d_g), C.c_void_p(stream)))
 
 
 def set_index(Z):

@@ -398,6 +398,46 @@ int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int3
     return NRLDPC_OK;
 }
 
+int nrldpc_crc_attach_dev(const nrldpc_tb_params* p, const uint8_t* d_a, int32_t n_tb, uint8_t* d_c, void* stream) {
+    int rc = check_tb_params(p);
+    if (rc) return rc;
+    if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (n_tb == 0) return NRLDPC_OK;
+    if (!d_a || !d_c) return fail(NRLDPC_ERR_ARG, "null pointer");
+    if ((p->tb_crc_len != 16 && p->tb_crc_len != 24) || (p->cb_crc_len != 0 && p->cb_crc_len != 24))
+        return fail(NRLDPC_ERR_UNSUPPORTED, "CRC lengths must be 16/24 (TB) and 0/24 (CB)");
+    if (p->B != p->A + p->tb_crc_len || p->C * (p->K_prime - p->cb_crc_len) != p->B)
+        return fail(NRLDPC_ERR_ARG, "B must equal A + L and C*(K' - L_cb)");
+    nrldpc::CrcAttachArgs a;
+    a.a = d_a; a.c = d_c; a.n_tb = n_tb; a.C = p->C; a.K = p->K; a.Kp = p->K_prime; a.Lcb = p->cb_crc_len;
+    a.A = p->A; a.B = p->B;
+    make_crc_plan(&a.tb, crc_poly_for(p->tb_crc_len, false), p->tb_crc_len, p->A);
+    make_crc_plan(&a.cb, crc_poly_for(24, true), 24, p->K_prime - p->cb_crc_len);
+    hipError_t e = nrldpc::launch_crc_attach(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hipfail(e, "CRC attach kernel launch");
+    return NRLDPC_OK;
+}
+
+int nrldpc_rate_match_dev(const nrldpc_tb_params* p, const uint8_t* d_cw, int32_t n_tb, uint8_t* d_g, void* stream) {
+    int rc = check_tb_params(p);
+    if (rc) return rc;
+    if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (n_tb == 0) return NRLDPC_OK;
+    if (!d_cw || !d_g) return fail(NRLDPC_ERR_ARG, "null pointer");
+    nrldpc::TxRmArgs a;
+    a.cw = d_cw; a.g = d_g; a.n_tb = n_tb; a.C = p->C; a.G = p->G; a.Z = p->Z; a.K = p->K; a.Kp = p->K_prime;
+    a.N = p->N; a.N_cb = p->N_cb; a.k0 = p->k_0; a.Qm = p->Q_m;
+    int off = 0;
+    for (int r = 0; r < p->C; ++r) {
+        if (p->E_r[r] < 0 || p->E_r[r] % p->Q_m) return fail(NRLDPC_ERR_UNSUPPORTED, "E_r must be a non-negative multiple of Q_m");
+        a.E[r] = p->E_r[r]; a.off[r] = off; off += p->E_r[r];
+    }
+    if (off != p->G) return fail(NRLDPC_ERR_ARG, "sum(E_r) must equal G");
+    hipError_t e = nrldpc::launch_rate_match(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hipfail(e, "rate-matching kernel launch");
+    return NRLDPC_OK;
+}
+
 int nrldpc_encode_dev(nrldpc_handle h, const uint8_t* d_info, int32_t batch, uint8_t* d_cw, void* stream) {
     if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");

@@ -79,6 +79,46 @@ __global__ __launch_bounds__(256) void nrldpc_crc_check_kernel(const CrcArgs a) 
     }
 }
 
+// Transmit side (NRLDPCEncoder.m:70-124): transport-block CRC attachment, segmentation into C code blocks,
+// CB-CRC24B attachment when C > 1, filler bits (NaN in the reference, encoded as 0, :120-122,153).
+// One workgroup per transport block.
+__global__ __launch_bounds__(256) void nrldpc_crc_attach_kernel(const CrcAttachArgs a) {
+    __shared__ uint32_t tbcrc;
+    const int tb = blockIdx.x;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint8_t* src = a.a + (size_t)tb * a.A;
+    uint8_t* c = a.c + (size_t)tb * a.C * a.K;
+    const int pay = a.Kp - a.Lcb, Ltb = a.B - a.A;
+    if (wave == 0) {
+        const uint32_t reg = wave_crc(src, a.A, a.tb); // NRLDPCEncoder.m:80-81
+        if ((threadIdx.x & 63) == 0) tbcrc = reg;
+    }
+    __syncthreads();
+    const uint32_t reg = tbcrc;
+    for (int i = threadIdx.x; i < a.C * a.K; i += blockDim.x) { // :104-122
+        const int r = i / a.K, k = i - r * a.K;
+        uint8_t bit = 0;
+        if (k < pay) {
+            const int s = r * pay + k; // position in b = [a; p]
+            bit = (s < a.A) ? (src[s] & 1u) : (uint8_t)((reg >> (Ltb - 1 - (s - a.A))) & 1u);
+        }
+        c[i] = bit; // CB CRC positions and fillers start as 0
+    }
+    __syncthreads();
+    if (a.C > 1) {
+        for (int r = wave; r < a.C; r += nw) { // :113-118
+            const uint32_t cr = wave_crc(c + (size_t)r * a.K, pay, a.cb);
+            const int lane = threadIdx.x & 63;
+            if (lane < a.Lcb) c[(size_t)r * a.K + pay + lane] = (uint8_t)((cr >> (a.Lcb - 1 - lane)) & 1u);
+        }
+    }
+}
+
+hipError_t launch_crc_attach(const CrcAttachArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(nrldpc_crc_attach_kernel, dim3(a.n_tb), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_crc_check(const CrcArgs& a, hipStream_t stream) {
     const size_t lds = 4 * (size_t)a.C + 16;
     hipLaunchKernelGGL(nrldpc_crc_check_kernel, dim3(a.n_tb), dim3(256), lds, stream, a);

@@ -66,5 +66,22 @@ struct CrcArgs {
 };
 hipError_t launch_crc_check(const CrcArgs& a, hipStream_t stream);
 
+struct CrcAttachArgs {
+    const uint8_t* a;   // [n_tb][A] payload bits
+    uint8_t* c;         // [n_tb*C][K] code blocks: payload (+ TB CRC) | CB CRC | zero fillers
+    int32_t n_tb, C, K, Kp, Lcb, A, B;
+    CrcPlan cb, tb;     // tb plan sized for A message bits, cb plan for K'-L_cb
+};
+hipError_t launch_crc_attach(const CrcAttachArgs& a, hipStream_t stream);
+
+struct TxRmArgs {
+    const uint8_t* cw;  // [n_tb*C][2Z+N] encoded code blocks
+    uint8_t* g;         // [n_tb][G] rate-matched, interleaved, concatenated bits
+    int32_t n_tb, C, G, Z, K, Kp, N, N_cb, k0, Qm;
+    int32_t E[NRLDPC_MAX_C];
+    int32_t off[NRLDPC_MAX_C];
+};
+hipError_t launch_rate_match(const TxRmArgs& a, hipStream_t stream);
+
 } // namespace nrldpc
 #endif

@@ -61,6 +61,38 @@ __global__ __launch_bounds__(256) void nrldpc_rate_recover_kernel(const RmArgs a
     else static_cast<float*>(a.out)[oi] = o;
 }
 
+// Transmit side: bit selection + interleaving + concatenation (NRLDPCEncoder.m:168-256) as one gather.
+// Output bit x of code block r is f(x) = e(i*E/Qm + j) with i = x mod Qm, j = x div Qm (:219-223), and
+// e(k) is the (k mod P)-th non-filler position of the circular buffer counted from k_0 (:186-195).
+__global__ __launch_bounds__(256) void nrldpc_rate_match_kernel(const TxRmArgs a) {
+    const int blk = blockIdx.y;
+    const int tb = blk / a.C, r = blk - tb * a.C;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int E = a.E[r];
+    if (x >= E) return;
+    const int rows = E / a.Qm;
+    const int k = (x % a.Qm) * rows + x / a.Qm;
+    const int lo_f = a.Kp - 2 * a.Z > 0 ? a.Kp - 2 * a.Z : 0, hi_f = a.K - 2 * a.Z;
+    const int f_hi = hi_f < a.N_cb ? hi_f : a.N_cb;
+    const int F = f_hi > lo_f ? f_hi - lo_f : 0;
+    const int P = a.N_cb - F;
+    auto nf = [&](int p) { int c = p - lo_f; c = c < 0 ? 0 : (c > F ? F : c); return p - c; };
+    int q = (k % P) + nf(a.k0);
+    if (q >= P) q -= P;
+    const int pos = (q < lo_f) ? q : q + F; // q-th non-filler position
+    const int ncwz = 2 * a.Z + a.N;
+    a.g[(size_t)tb * a.G + a.off[r] + x] = a.cw[(size_t)blk * ncwz + 2 * a.Z + pos] & 1u;
+}
+
+hipError_t launch_rate_match(const TxRmArgs& a, hipStream_t stream) {
+    int emax = 0;
+    for (int r = 0; r < a.C; ++r) emax = a.E[r] > emax ? a.E[r] : emax;
+    if (emax == 0) return hipSuccess;
+    dim3 grid((emax + 255) / 256, a.n_tb * a.C);
+    hipLaunchKernelGGL(nrldpc_rate_match_kernel, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_rate_recover(const RmArgs& a, hipStream_t stream) {
     const int ncwz = 2 * a.Z + a.N;
     dim3 grid((ncwz + 255) / 256, a.n_tb * a.C);

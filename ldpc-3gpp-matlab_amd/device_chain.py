@@ -81,3 +81,40 @@ class DeviceDecodeChain:
         ok = torch.empty(n_tb, dtype=torch.int32, device=self.dev)
         crc_check_dev(t, c_hat.data_ptr(), n_tb, b_hat.data_ptr(), ok.data_ptr(), None, stream)
         return b_hat[:, : p.A], ok != 0, iters.view(n_tb, C_)
+
+
+class DeviceEncodeChain:
+    """Batched NRLDPCEncoder.step on device tensors: CRC attachment + segmentation
+    (nrldpc_crc_attach_dev), LDPC encoding (nrldpc_encode_dev), rate matching (nrldpc_rate_match_dev).
+    The reference runs these as six interpreted stages per transport block (NRLDPCEncoder.m:60-67)."""
+
+    def __init__(self, params: NRLDPC, device_id=0):
+        import torch
+        from ._capi import crc_attach_dev, rate_match_dev
+        self.torch, self._crc_attach, self._rate_match = torch, crc_attach_dev, rate_match_dev
+        params.validate()
+        self.p = params
+        self.dev = torch.device("cuda", device_id)
+        self._codec = Codec(params.BG, params.Z_c, max_iter=1, llr_dtype=np.float32, device_id=device_id)
+
+    def close(self):
+        if self._codec is not None:
+            self._codec.close()
+            self._codec = None
+
+    def step(self, a):
+        """a: torch uint8 tensor [n_tb][A] on the device -> g: uint8 [n_tb][G]."""
+        torch, p = self.torch, self.p
+        if a.dim() != 2 or a.shape[1] != p.A or a.dtype != torch.uint8 or not a.is_cuda:
+            raise NRLDPCError("a should be a uint8 device tensor of shape [n_tb][A].")
+        a = a.contiguous()
+        n_tb = a.shape[0]
+        t = tb_params(p)
+        s = torch.cuda.current_stream().cuda_stream
+        c = torch.empty((n_tb * p.C, p.K), dtype=torch.uint8, device=self.dev)
+        self._crc_attach(t, a.data_ptr(), n_tb, c.data_ptr(), s)
+        cw = torch.empty((n_tb * p.C, 2 * p.Z_c + p.N), dtype=torch.uint8, device=self.dev)
+        self._codec.encode_dev(c.data_ptr(), n_tb * p.C, cw.data_ptr(), s)
+        g = torch.empty((n_tb, p.G), dtype=torch.uint8, device=self.dev)
+        self._rate_match(t, cw.data_ptr(), n_tb, g.data_ptr(), s)
+        return g

@@ -77,6 +77,72 @@ def demodulate_llr(rx, Q_m, N0):
     return out.reshape(rx.shape[:-1] + (-1,))
 
 
+def modulate_t(g, Q_m):
+    """torch version of `modulate` (device tensors)."""
+    import torch
+    if Q_m == 1:
+        return (1 - 2.0 * g.double()) * complex(np.cos(np.pi / 4), np.sin(np.pi / 4))
+    nb = Q_m // 2
+    amps, _ = _rail(nb)
+    norm = float(np.sqrt(2.0 * np.mean(amps ** 2)))
+    lut = torch.tensor(amps / norm, dtype=torch.float64, device=g.device)
+    b = g.reshape(g.shape[:-1] + (-1, Q_m)).long()
+    wi = sum(b[..., 2 * k] << (nb - 1 - k) for k in range(nb))
+    wq = sum(b[..., 2 * k + 1] << (nb - 1 - k) for k in range(nb))
+    return torch.complex(lut[wi], lut[wq])
+
+
+def demodulate_llr_t(rx, Q_m, N0):
+    """torch version of `demodulate_llr` (device tensors), exact log-MAP LLRs."""
+    import torch
+    if Q_m == 1:
+        rot = complex(np.cos(np.pi / 4), -np.sin(np.pi / 4))
+        return 4.0 * (rx * rot).real / N0
+    nb = Q_m // 2
+    amps, bits = _rail(nb)
+    norm = float(np.sqrt(2.0 * np.mean(amps ** 2)))
+    pts = torch.tensor(amps / norm, dtype=torch.float64, device=rx.device)
+    bt = torch.tensor(bits, device=rx.device)
+    out = torch.empty(rx.shape + (Q_m,), dtype=torch.float64, device=rx.device)
+    ninf = torch.tensor(float("-inf"), dtype=torch.float64, device=rx.device)
+    for rail, y in ((0, rx.real), (1, rx.imag)):
+        metric = -((y[..., None] - pts) ** 2) / N0
+        for k in range(nb):
+            m0 = torch.where(bt[:, k] == 0, metric, ninf)
+            m1 = torch.where(bt[:, k] == 1, metric, ninf)
+            out[..., 2 * k + rail] = torch.logsumexp(m0, dim=-1) - torch.logsumexp(m1, dim=-1)
+    return out.reshape(rx.shape[:-1] + (-1,))
+
+
+def simulate_point_device(enc_chain, dec_chain, Q_m, EsN0, rv_id_sequence, batch, gen):
+    """simulate_point with every stage on the GPU (rows N1-N4 of SURVEY.md section 8f): payload RNG, CRC
+    attachment, encoding, rate matching, modulation, AWGN, exact LLRs, rate recovery, decoding, CRC
+    check, error count.  enc_chain / dec_chain share one NRLDPC parameter object."""
+    import torch
+    p = enc_chain.p
+    dev = enc_chain.dev
+    a = torch.randint(0, 2, (batch, p.A), generator=gen, device=dev, dtype=torch.uint8)   # :118
+    N0 = 1.0 / 10.0 ** (EsN0 / 10.0)
+    ok = torch.zeros(batch, dtype=torch.bool, device=dev)
+    a_hat = torch.zeros((batch, p.A), dtype=torch.uint8, device=dev)
+    dec_chain.reset()                                                                      # :122
+    for rv in rv_id_sequence:                                                              # :124-137
+        p.rv_id = rv
+        g = enc_chain.step(a)
+        tx = modulate_t(g, Q_m)
+        noise = (N0 / 2.0) ** 0.5 * torch.complex(
+            torch.randn(tx.shape, generator=gen, device=dev, dtype=torch.float64),
+            torch.randn(tx.shape, generator=gen, device=dev, dtype=torch.float64))
+        g_tilde = demodulate_llr_t(tx + noise, Q_m, N0).float()
+        dec, good, _ = dec_chain.step(g_tilde)
+        newly = good & ~ok
+        a_hat[newly] = dec[newly]
+        ok |= good
+        if bool(ok.all()):
+            break
+    return (ok & (a_hat == a).all(dim=1)).cpu().numpy()
+
+
 def _num2str(x):
     """MATLAB num2str for the values used in the result file name (4 significant decimals, %g-like)."""
     if float(x) == int(x):
@@ -112,8 +178,9 @@ def simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng):
 
 def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0,), iterations=8,
                      target_block_errors=3, target_BLER=1e-3, EsN0_start=0.0, EsN0_delta=0.5, seed=0,
-                     results_dir="results", batch=256, max_points=200, decoder_kwargs=None):
+                     results_dir="results", batch=256, max_points=200, decoder_kwargs=None, device=False):
     """Same positional parameters and defaults as plot_BLER_vs_SNR.m:1,30-42 (no figure is drawn).
+    device=True keeps every stage on the GPU (simulate_point_device).
     Returns {(A, R, BG): [(EsN0, BLER, blocks), ...]}."""
     rng = np.random.default_rng(seed)                                # :45
     Q_m = Q_M.get(Modulation)
@@ -136,13 +203,24 @@ def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0
                     hDec = NRLDPCDecoder(A=a_len, BG=bg, G=G, Q_m=Q_m, I_HARQ=1, iterations=iterations,
                                          **(decoder_kwargs or {}))                                       # :99
                     hEnc.validate()
+                    if device:
+                        import torch
+                        from .device_chain import DeviceDecodeChain, DeviceEncodeChain
+                        from .nrldpc import NRLDPC
+                        shared = NRLDPC(A=a_len, BG=bg, G=G, Q_m=Q_m)
+                        tx_chain = DeviceEncodeChain(shared)
+                        rx_chain = DeviceDecodeChain(shared, iterations=iterations, I_HARQ=1, **(decoder_kwargs or {}))
+                        gen = torch.Generator(device="cuda")
+                        gen.manual_seed(int(seed))
                     with open(os.path.join(results_dir, name), "w") as fid:
                         BLER, EsN0, found_start = 1.0, float(EsN0_start), False                          # :84-88
                         while BLER > target_BLER and len(points) < max_points:                           # :104
                             blocks = errors = 0
                             keep_going = True
                             while keep_going and errors < target_block_errors:                           # :116
-                                for good in simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng):
+                                outcomes = (simulate_point_device(tx_chain, rx_chain, Q_m, EsN0, rv_id_sequence, batch, gen)
+                                            if device else simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng))
+                                for good in outcomes:
                                     if not found_start and not good:                                     # :139-141
                                         keep_going, BLER = False, 1.0
                                         break
@@ -159,6 +237,9 @@ def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0
                             EsN0 += EsN0_delta                                                           # :169
                     hEnc.release()
                     hDec.release()
+                    if device:
+                        tx_chain.close()
+                        rx_chain.close()
                 except UnsupportedParameters:                        # :172-176: skip this (A, R, BG)
                     continue
                 curves[(a_len, float(r), bg)] = points

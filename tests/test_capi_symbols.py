@@ -18,7 +18,8 @@ def declared_functions():
 def test_header_lists_the_boundary():
     names = declared_functions()
     for must in ("nrldpc_create", "nrldpc_decode", "nrldpc_decode_dev", "nrldpc_encode", "nrldpc_destroy",
-                 "nrldpc_strerror", "nrldpc_rate_recover_dev", "nrldpc_crc_check_dev"):
+                 "nrldpc_strerror", "nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_attach_dev",
+                 "nrldpc_rate_match_dev"):
         assert must in names
 
 
