@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t row_parity(char* lds, uint32_t zb, const Dec
 }
 
 template <int BG, int DT>
-__global__ __launch_bounds__(768) void nrldpc_decode_kernel(const DecArgs a, const int32_t* __restrict__ rot_tab) {
+__global__ __launch_bounds__(768, BG == 2 ? 6 : 3) void nrldpc_decode_kernel(const DecArgs a, const int32_t* __restrict__ rot_tab) {
     using G = BGD<BG>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;

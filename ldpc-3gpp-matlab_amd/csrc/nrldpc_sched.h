@@ -86,8 +86,13 @@ inline bool build_schedule(int bg, int Z, int n_layers, Schedule* s) {
     s->n_layers = n_layers;
     s->nc = g.kb + 4;
     s->ncp = s->nc | 1;
-    int ncw = 768 / Z; // 12 wave64 per workgroup at Z = 384: three per SIMD, evenly
+    // Codewords per workgroup: as many as fit 768 threads.  Consecutive ring positions of one codeword are
+    // ncw*ncp dwords apart in LDS and only an odd stride spreads a wave's lanes over all 32 banks: an even ncw
+    // means 2^k-way bank conflicts.  Measured (tools/bench_generic.py): up to 4-way is cheaper than a smaller
+    // workgroup (Z = 192, 320), beyond that an odd ncw wins by up to 3x (Z = 24: 32-way -> none).
+    int ncw = 768 / Z;
     if (ncw < 1) ncw = 1;
+    if (ncw > 4 && (ncw & 1) == 0) --ncw;
     s->ncw = ncw;
     s->threads = ((ncw * Z + 63) / 64) * 64;
     s->sbw = ncw * s->ncp * 4;
