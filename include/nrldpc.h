@@ -56,7 +56,7 @@ typedef struct nrldpc_cfg {
     int32_t max_iter;   /* 'MaximumIterationCount' (NRLDPCDecoder.m:41,120); 1..2000              */
     int32_t early_term; /* 1 = stop a codeword when all active parity checks hold (reference: 1)  */
     float alpha;        /* min-sum normalisation factor, 0 < alpha <= 1; 0 selects the default 0.75 */
-    int32_t llr_scale;  /* fixed-point units per unit LLR: 4, 8 or 16; 0 selects the default 8    */
+    int32_t llr_scale;  /* fixed-point units per unit LLR: power of two 1..32; 0 = default 8 */
     int32_t llr_dtype;  /* NRLDPC_LLR_*                                                            */
     int32_t device_id;  /* HIP device ordinal                                                      */
     int32_t max_batch;  /* staging capacity of the host entry points; 0 = grow on demand          */
