@@ -71,6 +71,15 @@ def test_z384_kernel_variants(pkg, orc, bg):
         run_case(pkg, orc, rng, bg, 384, B, 3.0, 7, nl=17, et=False, app=False)      # pruned, fixed iterations
 
 
+@pytest.mark.parametrize("bg,esn0", [(1, -1.6), (1, -1.2), (2, -1.4)])
+def test_headline_kernel_full_depth(pkg, orc, bg, esn0):
+    """The pipelined fixed-iteration kernel at the headline depth (25 iterations, every layer) in the waterfall,
+    where many codewords never converge and a-posteriori values grow large: every codeword vs the oracle."""
+    rng = np.random.default_rng(2500 + bg)
+    run_case(pkg, orc, rng, bg, 384, 97, esn0, 25, nl=0, et=False, app=False)
+    run_case(pkg, orc, rng, bg, 384, 33, esn0, 25, nl=0, et=True, app=True)
+
+
 def test_per_iteration_soft_llrs(pkg, orc):
     """Soft a-posteriori LLRs after 1, 2, ..., 8 iterations (tolerance: none, values are k/scale exactly)."""
     rng = np.random.default_rng(77)
