@@ -127,6 +127,21 @@ def test_special_llr_values(pkg, orc):
         assert (h[0] == info[0]).all() and it[4] == 1 and not h[4].any()
 
 
+def test_randomised_configurations(pkg, orc):
+    """Differential fuzz: random (BG, Z, active layers, iterations, alpha, scale, early termination, dtype, SNR,
+    batch) against the oracle -- hard bits, iteration counts and soft outputs."""
+    rng = np.random.default_rng(20260929)
+    for _ in range(60):
+        bg = int(rng.integers(1, 3))
+        Z = int(rng.choice(ALL_Z)) if rng.random() < 0.7 else 384
+        rows = BG_DIMS[bg][0]
+        nl = 0 if rng.random() < 0.4 else int(rng.integers(4, rows + 1))
+        run_case(pkg, orc, rng, bg, Z, int(rng.integers(1, 7)), float(rng.uniform(-2.0, 8.0)), int(rng.integers(1, 13)),
+                 nl=nl, et=bool(rng.integers(0, 2)), dt=[np.float16, np.float32][int(rng.integers(0, 2))],
+                 alpha=float(rng.choice([0.5, 0.625, 0.6875, 0.75, 0.8, 0.875, 1.0])),
+                 scale=int(rng.choice([2, 4, 8, 16])), app=bool(rng.integers(0, 2)))
+
+
 def test_golden_fixture_on_gpu(pkg):
     g = np.load(os.path.join(GOLD, "nmsq_golden.npz"))
     for name in sorted(set(k.split("/")[0] for k in g.files)):
