@@ -1,15 +1,23 @@
-"""Build recipe for libnrldpc_hip.so (gfx950 only; hipcc cross-compiles without a GPU)."""
+"""Build recipe for libnrldpc_hip.so (gfx950 only; hipcc cross-compiles without a GPU).
+
+Every translation unit is compiled to an object in parallel (the compile-time-Z decoder is instantiated
+once per (BG, Z) pair from one source with -D flags), then linked into one in-tree shared object.
+"""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip.so")  # env override: kernel experiments
-SOURCES = ["nrldpc_decode.hip", "nrldpc_decode_z64.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip",
-           "nrldpc_crc.hip", "nrldpc_capi.hip"]
-HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h"]
+OBJDIR = os.path.join(HERE, "build")
+SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_capi.hip"]
+Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
+Z64_PAIRS = [(bg, z) for bg in (1, 2) for z in (64, 128, 192, 256, 320, 384)]  # keep in sync with NRLDPC_Z64_LIST
+HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def _hipcc():
@@ -19,24 +27,47 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the MI355X library cannot be built (there is no CPU fallback)")
 
 
+def _deps():
+    d = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + [Z64_SOURCE]]
+    d += [os.path.join(INCLUDE, "nrldpc.h"), os.path.join(INCLUDE, "nr_bg_tables.h"), os.path.abspath(__file__)]
+    return [p for p in d if os.path.exists(p)]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS if os.path.exists(os.path.join(CSRC, f))]
-    deps += [os.path.join(INCLUDE, "nrldpc.h"), os.path.join(INCLUDE, "nr_bg_tables.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build_lib(force=False, verbose=False):
-    """Compile every HIP source into one shared object, in-tree."""
+def build_lib(force=False, verbose=False, jobs=None):
+    """Compile every HIP source (objects in parallel) and link one shared object, in-tree."""
     if not force and not _stale():
         return LIB
-    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-I" + CSRC, *srcs, "-o", LIB + ".tmp"]
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    inc = ["-I" + INCLUDE, "-I" + CSRC]
+    units = [(os.path.join(CSRC, f), os.path.join(OBJDIR, f.replace(".hip", ".o")), []) for f in SOURCES]
+    units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d.o" % (bg, z)),
+               ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64_PAIRS]
+    newest = max(os.path.getmtime(d) for d in _deps())
+
+    def compile_one(u):
+        src, obj, defs = u
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
+            return obj
+        cmd = [hipcc, *FLAGS, *inc, *defs, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    jobs = jobs or min(len(units), max(1, (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(compile_one, units))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB

@@ -236,7 +236,9 @@ template <int BG, int DT> static hipError_t launch_t(const DecArgs& a, int grid,
 }
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
-    if (a.Z == 384) return launch_decode_z384(bg, a, stream);
+#define NRLDPC_Z64_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64_##b##_##z(a, stream);
+    NRLDPC_Z64_LIST(NRLDPC_Z64_CASE)
+#undef NRLDPC_Z64_CASE
     const int grid = (a.batch + a.ncw - 1) / a.ncw;
     const bool f16 = a.llr_kind == NRLDPC_K_F16;
     if (bg == 1)

@@ -1,4 +1,5 @@
-// nrldpc_decode_z64.hip -- compile-time-Z specialisation of the layered NMS-Q decoder (Z = 384).
+// nrldpc_decode_z64.h -- compile-time-Z specialisation of the layered NMS-Q decoder (Z a multiple of 64).
+// Instantiated once per (BG, Z) by nrldpc_decode_z64_inst.hip (compiled with -DNRLDPC_Z64_BG / -DNRLDPC_Z64_Z).
 //
 // Same algorithm and results as nrldpc_decode.hip (the generic kernel is the reference for this one
 // in tests); what changes is where the circulant rotation is paid.  gfx950 issues add/sub/mul/fma and
@@ -21,6 +22,8 @@
 //     column's guard).  Both are wave-uniform branches on compile-time constants; no lane masks.
 #include <cstdlib>
 
+#ifndef NRLDPC_DECODE_Z64_H
+#define NRLDPC_DECODE_Z64_H
 #include "nrldpc_device.h"
 
 namespace nrldpc {
@@ -32,7 +35,14 @@ constexpr int z64_set_index(int Z) {
     return -1;
 }
 
-template <int BG, int ZC, int NCWG_ = 768 / ZC> struct Z64 : BGD<BG> {
+// codewords per workgroup: as many as fit 768 threads and the 160 KB of LDS
+template <int BG, int ZC> constexpr int z64_ncwg() {
+    constexpr int cws = (BGT<BG>::KB + 4) * (256 + (ZC + 64) * 4);
+    constexpr int by_lds = (160 * 1024 - 512) / cws;
+    return (768 / ZC) < by_lds ? (768 / ZC) : by_lds;
+}
+
+template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>()> struct Z64 : BGD<BG> {
     static_assert(ZC % 64 == 0, "specialisation needs whole waves per codeword");
     static constexpr int NWV = ZC / 64;                 // waves per codeword
     static constexpr int GUARD = 256;                   // bytes: 64 never-read words in front of every ring
@@ -559,11 +569,5 @@ template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& 
     return launch_z64f<BG, ZC, NCWG, true, true>(a, s);
 }
 
-hipError_t launch_decode_z384(int bg, const DecArgs& a, hipStream_t stream) {
-    // Two codewords (12 waves, three per SIMD) per workgroup, one workgroup per CU.  One codeword per
-    // workgroup with two workgroups per CU measured 15 % slower: the dispatcher leaves the second slot of a
-    // CU empty ~15-20 % of the time (tools/ubench/occ_probe.hip).
-    return bg == 1 ? launch_z64<1, 384, 2>(a, stream) : launch_z64<2, 384, 2>(a, stream);
-}
-
 } // namespace nrldpc
+#endif

@@ -21,7 +21,11 @@ struct DecArgs {
 };
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_decode_z384(int bg, const DecArgs& a, hipStream_t stream); // compile-time-Z specialisation
+// compile-time-Z specialisations (nrldpc_decode_z64_inst.hip), one per (BG, Z) with Z a multiple of 64
+#define NRLDPC_Z64_LIST(X) X(1, 64) X(1, 128) X(1, 192) X(1, 256) X(1, 320) X(1, 384) X(2, 64) X(2, 128) X(2, 192) X(2, 256) X(2, 320) X(2, 384)
+#define NRLDPC_Z64_DECL(bg, z) hipError_t launch_decode_z64_##bg##_##z(const DecArgs& a, hipStream_t stream);
+NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
+#undef NRLDPC_Z64_DECL
 
 struct EncArgs {
     const uint8_t* info; // [batch][kb*Z]
