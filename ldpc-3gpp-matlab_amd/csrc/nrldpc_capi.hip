@@ -329,21 +329,25 @@ static uint32_t xpow_mod(uint32_t poly, int L, long n) {
     return v;
 }
 
-static void make_crc_plan(nrldpc::CrcPlan* pl, uint32_t poly, int L, int len) {
-    pl->poly = poly; pl->L = L;
-    pl->chunk = (len + 63) / 64;
-    if (pl->chunk < 1) pl->chunk = 1;
-    for (int s = 0; s < 6; ++s) {
-        const long n = (long)pl->chunk << s;
-        uint32_t v = xpow_mod(poly, L, n); // x^n
-        const uint32_t top = 1u << (L - 1), mask = (1u << L) - 1u;
-        for (int b = 0; b < 24; ++b) {
-            pl->shiftmat[s][b] = (b < L) ? v : 0u; // x^(n+b)
-            const bool carry = v & top;
-            v = (v << 1) & mask;
-            if (carry) v ^= poly & mask;
-        }
+static void xpow_matrix(uint32_t* M, uint32_t poly, int L, long n) {
+    const uint32_t top = 1u << (L - 1), mask = (1u << L) - 1u;
+    uint32_t v = xpow_mod(poly, L, n); // x^n
+    for (int b = 0; b < 24; ++b) {
+        M[b] = (b < L) ? v : 0u; // x^(n+b)
+        const bool carry = v & top;
+        v = (v << 1) & mask;
+        if (carry) v ^= poly & mask;
     }
+}
+
+// Plan for wave-parallel CRCs over messages of up to `len` bits; seg / seg_tail are the segment lengths of
+// the cross-code-block fold (nrldpc_crc.hip).  An odd chunk keeps the 64 lanes' LDS reads on distinct banks.
+static void make_crc_plan(nrldpc::CrcPlan* pl, uint32_t poly, int L, int len, int seg, int seg_tail) {
+    pl->poly = poly; pl->L = L;
+    pl->chunk = ((len + 63) / 64) | 1;
+    for (int s = 0; s < 6; ++s) xpow_matrix(pl->shiftmat[s], poly, L, (long)pl->chunk << s);
+    xpow_matrix(pl->horner, poly, L, seg);
+    xpow_matrix(pl->horner_tail, poly, L, seg_tail);
 }
 
 static int check_tb_params(const nrldpc_tb_params* p) {
@@ -391,8 +395,9 @@ int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int3
     nrldpc::CrcArgs a;
     a.c_hat = d_c_hat; a.b_hat = d_b_hat; a.ok = d_ok; a.cb_pass = d_cb_pass;
     a.n_tb = n_tb; a.C = p->C; a.K = p->K; a.Kp = p->K_prime; a.Lcb = p->cb_crc_len; a.A = p->A; a.B = p->B;
-    make_crc_plan(&a.tb, crc_poly_for(p->tb_crc_len, false), p->tb_crc_len, p->B);
-    make_crc_plan(&a.cb, crc_poly_for(24, true), 24, p->K_prime);
+    const int pay = p->K_prime - p->cb_crc_len;
+    make_crc_plan(&a.tb, crc_poly_for(p->tb_crc_len, false), p->tb_crc_len, pay, pay, pay);
+    make_crc_plan(&a.cb, crc_poly_for(24, true), 24, p->K_prime, 0, 0);
     hipError_t e = nrldpc::launch_crc_check(a, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hipfail(e, "CRC kernel launch");
     return NRLDPC_OK;
@@ -411,8 +416,10 @@ int nrldpc_crc_attach_dev(const nrldpc_tb_params* p, const uint8_t* d_a, int32_t
     nrldpc::CrcAttachArgs a;
     a.a = d_a; a.c = d_c; a.n_tb = n_tb; a.C = p->C; a.K = p->K; a.Kp = p->K_prime; a.Lcb = p->cb_crc_len;
     a.A = p->A; a.B = p->B;
-    make_crc_plan(&a.tb, crc_poly_for(p->tb_crc_len, false), p->tb_crc_len, p->A);
-    make_crc_plan(&a.cb, crc_poly_for(24, true), 24, p->K_prime - p->cb_crc_len);
+    const int pay = p->K_prime - p->cb_crc_len;
+    if (pay < p->tb_crc_len) return fail(NRLDPC_ERR_UNSUPPORTED, "code block shorter than the transport-block CRC");
+    make_crc_plan(&a.tb, crc_poly_for(p->tb_crc_len, false), p->tb_crc_len, pay, pay, pay - p->tb_crc_len);
+    make_crc_plan(&a.cb, crc_poly_for(24, true), 24, pay, 0, 0);
     hipError_t e = nrldpc::launch_crc_attach(a, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hipfail(e, "CRC attach kernel launch");
     return NRLDPC_OK;

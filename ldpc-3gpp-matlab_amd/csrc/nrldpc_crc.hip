@@ -5,11 +5,17 @@
 // decoder kernel) -> b_hat [n_tb][B] bytes (a_hat is its first A bytes) + one ok flag per transport block
 // (ok = 0 is the reference's a_hat = []).
 //
-// One wave64 per code block / transport block.  Each lane runs the bit-serial CRC register over its own
-// contiguous chunk; chunks are then combined pairwise in a log2(64) tree with
-//     crc(A || B) = crc(A) * x^|B| mod g  xor  crc(B),
-// the multiplication by x^(chunk * 2^s) being a precomputed 24x24 GF(2) matrix per tree level (host side,
-// from the polynomial of get_3gpp_crc_polynomial.m:3-14).  Zero initial state => leading zero padding is free.
+// One workgroup per transport block, one wave64 per code block (waves loop when C > 4).  A wave stages its
+// code block into LDS with coalesced 16-byte loads (every HBM byte is read once and written once; the
+// stages are HBM-bound copies), then:
+//   * each lane runs the bit-serial CRC register over its own contiguous chunk of the LDS copy, and the 64
+//     chunk remainders are combined pairwise in a log2(64) tree with
+//         crc(A || B) = crc(A) * x^|B| mod g  xor  crc(B),
+//     the multiplication by x^(chunk * 2^s) being a precomputed 24x24 GF(2) matrix per tree level (host side,
+//     from the polynomial of get_3gpp_crc_polynomial.m:3-14).  Zero initial state => leading zeros are free;
+//   * the transport-block CRC is never computed over the concatenated payload: every wave also takes the
+//     TB-polynomial remainder of its own payload segment, and the C segment remainders are folded by Horner's
+//     rule with the x^(segment length) matrix -- the same identity, applied across code blocks.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,19 +29,65 @@ __device__ __forceinline__ uint32_t gf2_apply(const uint32_t* M, uint32_t v, int
     return o;
 }
 
-// CRC remainder of `len` bits (one per byte, stride 1) by one wave; every lane returns the result.
+// LDS written by some lanes of a wave is read by other lanes of the same wave: DS instructions of one wave
+// execute in issue order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Copy n bytes global -> LDS by one wave with 16-byte loads whatever the source alignment: the LDS copy is
+// placed at the same offset modulo 16 as the source (`base` is 16-byte aligned with 16 bytes of slack), so
+// only the first and last few bytes move one at a time.  Returns the LDS address of byte 0.
+__device__ __forceinline__ uint8_t* stage_row(uint8_t* base, const uint8_t* src, int n) {
+    const int lane = threadIdx.x & 63;
+    const int sh = (int)(reinterpret_cast<uintptr_t>(src) & 15);
+    uint8_t* dst = base + sh;
+    int head = (16 - sh) & 15;
+    head = head < n ? head : n;
+    if (lane < head) dst[lane] = src[lane];
+    const int nv = (n - head) >> 4;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src + head);
+    uint4* d4 = reinterpret_cast<uint4*>(dst + head);
+    for (int i = lane; i < nv; i += 64) d4[i] = s4[i];
+    const int done = head + (nv << 4);
+    if (lane < n - done) dst[done + lane] = src[done + lane];
+    return dst;
+}
+
+// Copy n bytes LDS -> global by one wave with dword stores whatever the two alignments (an unaligned LDS
+// dword is two aligned reads + v_alignbyte; up to 4 bytes past the end are read, never stored), masking
+// every byte to its bit.
+__device__ __forceinline__ void store_row(uint8_t* dst, const uint8_t* src, int n) {
+    const int lane = threadIdx.x & 63;
+    int head = (4 - (int)(reinterpret_cast<uintptr_t>(dst) & 3)) & 3;
+    head = head < n ? head : n;
+    if (lane < head) dst[lane] = src[lane] & 1u;
+    const int nv = (n - head) >> 2;
+    const uintptr_t so = reinterpret_cast<uintptr_t>(src + head);
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(so & ~(uintptr_t)3);
+    const uint32_t rot = (uint32_t)(so & 3);
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+    for (int i = lane; i < nv; i += 64)
+        d32[i] = __builtin_amdgcn_alignbyte(s32[i + 1], s32[i], rot) & 0x01010101u;
+    const int done = head + (nv << 2);
+    if (lane < n - done) dst[done + lane] = src[done + lane] & 1u;
+}
+
+// CRC remainder of `len` bits (one per byte, in LDS) by one wave; every lane returns the result.
+// pl.chunk bits per lane with 64 * chunk >= len; the shortfall acts as leading zeros.
 __device__ __forceinline__ uint32_t wave_crc(const uint8_t* bits, int len, const CrcPlan& pl) {
     const int lane = threadIdx.x & 63;
-    const int chunk = pl.chunk;                       // bits per lane; 64*chunk >= len
-    const int pad = 64 * chunk - len;                 // virtual leading zeros
-    const uint32_t top = 1u << (pl.L - 1), mask = (1u << pl.L) - 1u;
+    const int chunk = pl.chunk;
+    const int pad = 64 * chunk - len;
+    const uint32_t top = 1u << (pl.L - 1), mask = (1u << pl.L) - 1u, poly = pl.poly & mask;
     uint32_t reg = 0;
-    int i0 = lane * chunk - pad;
-    for (int i = i0; i < i0 + chunk; ++i) {
-        const uint32_t bit = (i >= 0) ? (bits[i] & 1u) : 0u;
-        const uint32_t fb = ((reg & top) ? 1u : 0u) ^ bit;
+    const int i0 = lane * chunk - pad;
+    for (int i = i0 < 0 ? 0 : i0; i < i0 + chunk; ++i) {
+        const uint32_t fb = ((reg & top) ? 1u : 0u) ^ (bits[i] & 1u);
         reg = (reg << 1) & mask;
-        if (fb) reg ^= pl.poly & mask;
+        reg ^= fb ? poly : 0u;
     }
     // tree: after level s, lanes that are multiples of 2^(s+1) hold the CRC of 2^(s+1) chunks
 #pragma unroll
@@ -46,82 +98,100 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* bits, int len, const
     return __shfl(reg, 0, 64);
 }
 
-// One workgroup of 256 threads (4 waves) per transport block: the waves share the C code-block CRCs and the
-// payload copy into b_hat (global: transport blocks can exceed LDS), then wave 0 checks the transport block.
+__host__ __device__ __forceinline__ int row_capacity(int K) { return ((K + 15) & ~15) + 48; }
+
 __global__ __launch_bounds__(256) void nrldpc_crc_check_kernel(const CrcArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    int* cb_fail = reinterpret_cast<int*>(lds); // [C]
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+    const int cap = row_capacity(a.K);
+    uint8_t* base = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * cap;
+    int* cb_fail = reinterpret_cast<int*>(lds + (size_t)nw * cap);  // [C]
+    uint32_t* part = reinterpret_cast<uint32_t*>(cb_fail + a.C);    // [C] TB-polynomial remainder per segment
     const int tb = blockIdx.x;
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint8_t* chat = a.c_hat + (size_t)tb * a.C * a.K;
     uint8_t* b_hat = a.b_hat + (size_t)tb * a.B;
     const int pay = a.Kp - a.Lcb; // payload bits per code block
     for (int r = wave; r < a.C; r += nw) {
+        wave_lds_sync(); // previous round's readers are done with the row
+        const uint8_t* row = stage_row(base, chat + (size_t)r * a.K, a.Kp);
+        wave_lds_sync();
         int fail = 0;
-        if (a.C > 1) fail = wave_crc(chat + (size_t)r * a.K, a.Kp, a.cb) != 0; // NRLDPCDecoder.m:298-301
-        if ((threadIdx.x & 63) == 0) cb_fail[r] = fail;
-    }
-    for (int i = threadIdx.x; i < a.C * pay; i += blockDim.x) { // :303-309 payload copy
-        const int r = i / pay, k = i - r * pay;
-        b_hat[i] = chat[(size_t)r * a.K + k] & 1u;
+        if (a.C > 1) fail = wave_crc(row, a.Kp, a.cb) != 0;  // NRLDPCDecoder.m:298-301
+        const uint32_t p = wave_crc(row, pay, a.tb);
+        if (lane == 0) { cb_fail[r] = fail; part[r] = p; }
+        store_row(b_hat + (size_t)r * pay, row, pay);       // :303-309 payload copy
     }
     __syncthreads();
     if (wave == 0) {
-        const int tb_fail = wave_crc(b_hat, a.B, a.tb) != 0; // :336
+        uint32_t reg = 0;                                    // :336 over b_hat = segment 0 || ... || segment C-1
+        for (int r = 0; r < a.C; ++r) reg = gf2_apply(a.tb.horner, reg, a.tb.L) ^ part[r];
         int any_cb = 0;
-        for (int r = threadIdx.x & 63; r < a.C; r += 64) any_cb |= cb_fail[r];
+        for (int r = lane; r < a.C; r += 64) any_cb |= cb_fail[r];
         any_cb = __any(any_cb);
-        if ((threadIdx.x & 63) == 0) {
-            a.ok[tb] = (tb_fail || any_cb) ? 0 : 1; // :337-339
-            if (a.cb_pass)
-                for (int r = 0; r < a.C; ++r) a.cb_pass[(size_t)tb * a.C + r] = cb_fail[r] ? 0 : 1;
-        }
+        if (lane == 0) a.ok[tb] = (reg != 0 || any_cb) ? 0 : 1; // :337-339
+        if (a.cb_pass)
+            for (int r = lane; r < a.C; r += 64) a.cb_pass[(size_t)tb * a.C + r] = cb_fail[r] ? 0 : 1;
     }
 }
 
 // Transmit side (NRLDPCEncoder.m:70-124): transport-block CRC attachment, segmentation into C code blocks,
 // CB-CRC24B attachment when C > 1, filler bits (NaN in the reference, encoded as 0, :120-122,153).
-// One workgroup per transport block.
+// Same structure: one wave per code block; the last code block (which carries the transport-block CRC bits)
+// is finished after the segment remainders of all code blocks have been folded.
 __global__ __launch_bounds__(256) void nrldpc_crc_attach_kernel(const CrcAttachArgs a) {
-    __shared__ uint32_t tbcrc;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+    const int cap = row_capacity(a.K);
+    uint8_t* base = reinterpret_cast<uint8_t*>(lds) + (size_t)wave * cap;
+    uint8_t* row = base;
+    uint32_t* part = reinterpret_cast<uint32_t*>(lds + (size_t)nw * cap); // [C]
     const int tb = blockIdx.x;
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint8_t* src = a.a + (size_t)tb * a.A;
     uint8_t* c = a.c + (size_t)tb * a.C * a.K;
     const int pay = a.Kp - a.Lcb, Ltb = a.B - a.A;
-    if (wave == 0) {
-        const uint32_t reg = wave_crc(src, a.A, a.tb); // NRLDPCEncoder.m:80-81
-        if ((threadIdx.x & 63) == 0) tbcrc = reg;
+    auto finish = [&](int r) { // payload complete in row[0..pay): CB CRC (:113-118), fillers (:120-122), store
+        if (a.C > 1) {
+            const uint32_t cr = wave_crc(row, pay, a.cb);
+            if (lane < a.Lcb) row[pay + lane] = (uint8_t)((cr >> (a.Lcb - 1 - lane)) & 1u);
+        }
+        for (int i = a.Kp + lane; i < a.K; i += 64) row[i] = 0;
+        wave_lds_sync();
+        store_row(c + (size_t)r * a.K, row, a.K);
+    };
+    for (int r = wave; r < a.C; r += nw) {
+        const bool last = (r == a.C - 1);
+        const int seg = last ? pay - Ltb : pay; // bits of `a` in this code block (:104-112)
+        wave_lds_sync();
+        row = stage_row(base, src + (size_t)r * pay, seg);
+        wave_lds_sync();
+        const uint32_t p = wave_crc(row, seg, a.tb);
+        if (lane == 0) part[r] = p;
+        if (!last) finish(r);
     }
     __syncthreads();
-    const uint32_t reg = tbcrc;
-    for (int i = threadIdx.x; i < a.C * a.K; i += blockDim.x) { // :104-122
-        const int r = i / a.K, k = i - r * a.K;
-        uint8_t bit = 0;
-        if (k < pay) {
-            const int s = r * pay + k; // position in b = [a; p]
-            bit = (s < a.A) ? (src[s] & 1u) : (uint8_t)((reg >> (Ltb - 1 - (s - a.A))) & 1u);
-        }
-        c[i] = bit; // CB CRC positions and fillers start as 0
-    }
-    __syncthreads();
-    if (a.C > 1) {
-        for (int r = wave; r < a.C; r += nw) { // :113-118
-            const uint32_t cr = wave_crc(c + (size_t)r * a.K, pay, a.cb);
-            const int lane = threadIdx.x & 63;
-            if (lane < a.Lcb) c[(size_t)r * a.K + pay + lane] = (uint8_t)((cr >> (a.Lcb - 1 - lane)) & 1u);
-        }
+    if (wave == (a.C - 1) % nw) { // this wave's row still holds the last code block's share of `a`
+        uint32_t reg = 0;         // NRLDPCEncoder.m:80-81 over a = segment 0 || ... || tail
+        for (int r = 0; r + 1 < a.C; ++r) reg = gf2_apply(a.tb.horner, reg, a.tb.L) ^ part[r];
+        reg = gf2_apply(a.tb.horner_tail, reg, a.tb.L) ^ part[a.C - 1];
+        if (lane < Ltb) row[pay - Ltb + lane] = (uint8_t)((reg >> (Ltb - 1 - lane)) & 1u);
+        wave_lds_sync();
+        finish(a.C - 1);
     }
 }
 
+static int waves_for(int C) { return C < 4 ? C : 4; }
+
 hipError_t launch_crc_attach(const CrcAttachArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(nrldpc_crc_attach_kernel, dim3(a.n_tb), dim3(256), 0, stream, a);
+    const int nw = waves_for(a.C);
+    const size_t lds = (size_t)nw * row_capacity(a.K) + 4 * (size_t)a.C + 16;
+    hipLaunchKernelGGL(nrldpc_crc_attach_kernel, dim3(a.n_tb), dim3(64 * nw), lds, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_crc_check(const CrcArgs& a, hipStream_t stream) {
-    const size_t lds = 4 * (size_t)a.C + 16;
-    hipLaunchKernelGGL(nrldpc_crc_check_kernel, dim3(a.n_tb), dim3(256), lds, stream, a);
+    const int nw = waves_for(a.C);
+    const size_t lds = (size_t)nw * row_capacity(a.K) + 8 * (size_t)a.C + 16;
+    hipLaunchKernelGGL(nrldpc_crc_check_kernel, dim3(a.n_tb), dim3(64 * nw), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -59,6 +59,8 @@ struct CrcPlan {
     uint32_t poly;            // generator with the x^L term
     int32_t L, chunk;         // CRC length, bits per lane (64*chunk >= message length)
     uint32_t shiftmat[6][24]; // level s: column b = x^(b + chunk*2^s) mod g
+    uint32_t horner[24];      // column b = x^(b + segment length) mod g: folds per-code-block remainders
+    uint32_t horner_tail[24]; // same for the last (shorter) segment of the transmit side
 };
 struct CrcArgs {
     const uint8_t* c_hat;     // [n_tb*C][K] decoded code blocks
@@ -74,7 +76,7 @@ struct CrcAttachArgs {
     const uint8_t* a;   // [n_tb][A] payload bits
     uint8_t* c;         // [n_tb*C][K] code blocks: payload (+ TB CRC) | CB CRC | zero fillers
     int32_t n_tb, C, K, Kp, Lcb, A, B;
-    CrcPlan cb, tb;     // tb plan sized for A message bits, cb plan for K'-L_cb
+    CrcPlan cb, tb;     // both sized for one code block's payload K'-L_cb (the TB CRC is folded from segments)
 };
 hipError_t launch_crc_attach(const CrcAttachArgs& a, hipStream_t stream);
 

@@ -7,7 +7,7 @@
 // HBM -> codeword LLR blocks [n_tb*C][ncols*Z] ready for nrldpc_decode_dev, no host loop in between.
 //
 // The reference walks the circular buffer bit by bit (O(E) interpreted iterations per block); here each
-// thread owns one output position p and gathers:  the q-th non-filler position from k_0 receives
+// thread owns pairs of adjacent output positions p and gathers:  the q-th non-filler position from k_0 receives
 // e[q], e[q+P], e[q+2P], ... (P = non-filler positions in the buffer), added in ascending order -- the
 // reference's accumulation order -- and e[k] = f[(k mod E/Qm)*Qm + k div (E/Qm)].  HBM-bound gather:
 // every g_tilde word is read exactly once (reads of one block interleave Qm streams), every output word
@@ -20,83 +20,145 @@
 
 namespace nrldpc {
 
+template <typename T> __device__ __forceinline__ T to_out(float v);
+template <> __device__ __forceinline__ float to_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half to_out<__half>(float v) { return __float2half(v); }
+
+constexpr int RR_PAIRS = 4;                    // position pairs per thread
+constexpr int RR_TILE = 64 * 2 * RR_PAIRS;     // positions per wave: 4 sweeps of 128 consecutive positions
+
+// Thread mapping: in sweep s a wave covers 128 consecutive positions, lane l the pair (2l, 2l+1) -- a 4-byte
+// (fp16) or 8-byte store per lane, 256 / 512 contiguous bytes per wave instruction, and g_tilde reads that
+// advance by 2*Qm floats from lane to lane (the two reads of a pair fill the gaps).
+template <typename OutT>
 __global__ __launch_bounds__(256) void nrldpc_rate_recover_kernel(const RmArgs a) {
     const int blk = blockIdx.y;              // tb * C + r
     const int tb = blk / a.C, r = blk - tb * a.C;
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x; // position in the core's input, 0 .. 2Z+N-1
     const int ncwz = 2 * a.Z + a.N;
-    if (pos >= ncwz) return;
-    float val = 0.0f;
-    bool filler = false;
-    if (pos >= 2 * a.Z) {
-        const int p = pos - 2 * a.Z;
-        const int lo_f = a.Kp - 2 * a.Z > 0 ? a.Kp - 2 * a.Z : 0, hi_f = a.K - 2 * a.Z; // fillers (:224)
-        filler = (p >= lo_f && p < hi_f);
-        if (!filler && p < a.N_cb) {
-            // fillers that lie inside the circular buffer, and non-filler count before a position
-            const int f_hi = hi_f < a.N_cb ? hi_f : a.N_cb;
-            const int F = f_hi > lo_f ? f_hi - lo_f : 0;
-            const int P = a.N_cb - F;
-            auto nf = [&](int x) { int c = x - lo_f; c = c < 0 ? 0 : (c > F ? F : c); return x - c; };
-            int q = nf(p) - nf(a.k0);
-            if (q < 0) q += P;
-            const int E = a.E[r];
-            if (E > 0) {
-                const int rows = E / a.Qm;
-                const float* f = a.g + (size_t)tb * a.G + a.off[r];
-                for (int k = q; k < E; k += P) val += f[(k % rows) * a.Qm + k / rows];
+    const int lane = threadIdx.x & 63;
+    const int tile0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RR_TILE;
+    if (tile0 >= ncwz) return;
+    const int lo_f = a.Kp - 2 * a.Z > 0 ? a.Kp - 2 * a.Z : 0, hi_f = a.K - 2 * a.Z; // fillers (:224)
+    // fillers that lie inside the circular buffer, and non-filler count before a position
+    const int f_hi = hi_f < a.N_cb ? hi_f : a.N_cb;
+    const int F = f_hi > lo_f ? f_hi - lo_f : 0;
+    const int P = a.N_cb - F;
+    auto nf = [&](int x) { int c = x - lo_f; c = c < 0 ? 0 : (c > F ? F : c); return x - c; };
+    const int nfk0 = nf(a.k0);
+    const int E = a.E[r];
+    const int rows = E > 0 ? E / a.Qm : 1;
+    const int Pq = P / rows, Pr = P - Pq * rows;  // a repetition is P positions of e further on
+    const float* f = a.g + (size_t)tb * a.G + a.off[r];
+    float* hb = a.harq ? a.harq + (size_t)blk * a.N_cb : nullptr;
+    OutT* out = static_cast<OutT*>(a.out) + (size_t)blk * ncwz;
+    const bool vec = (ncwz % 2) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+#pragma unroll
+    for (int s = 0; s < RR_PAIRS; ++s) {
+        const int pos0 = tile0 + s * 128 + 2 * lane;
+        if (pos0 >= ncwz) break;
+        OutT o[2];
+        // q: index among the buffer's non-filler positions counted from k_0; e index q = i*rows + j
+        int q = -1, j = 0, i = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int p = pos0 + t - 2 * a.Z;
+            float val = 0.0f;
+            const bool filler = (p >= lo_f && p < hi_f);
+            if (p >= 0 && !filler && p < a.N_cb) {
+                if (q < 0) {
+                    q = nf(p) - nfk0;
+                    if (q < 0) q += P;
+                    for (int m = 1; m < a.Qm; ++m) i += (q >= m * rows); // q / rows when q < E = Qm * rows
+                    j = q - i * rows;
+                }
+                if (q < E) {
+                    val = f[j * a.Qm + i];
+                    int jj = j, ii = i;
+                    for (int k = q + P; k < E; k += P) { // soft combining of repetitions, ascending k (:229-231)
+                        jj += Pr; ii += Pq;
+                        if (jj >= rows) { jj -= rows; ++ii; }
+                        val += f[jj * a.Qm + ii];
+                    }
+                }
+                if (hb) { // :236-239
+                    val += hb[p];
+                    hb[p] = val;
+                }
+                ++q; ++j;
+                if (j == rows) { j = 0; ++i; }
+                if (q == P) { q = 0; j = 0; i = 0; }
             }
-            if (a.harq) {
-                float* hb = a.harq + ((size_t)blk) * a.N_cb + p;
-                val += *hb;
-                *hb = val;
-            }
-        } else if (filler && p < a.N_cb && a.harq) {
-            // the reference stores NaN here; the position is forced to +inf every time, nothing to keep
+            // (fillers inside the buffer: the reference keeps NaN there; the position is forced to +inf every time)
+            o[t] = to_out<OutT>(filler ? __builtin_inff() : val);
+        }
+        if (vec) {
+            struct alignas(2 * sizeof(OutT)) Pair { OutT x, y; };
+            *reinterpret_cast<Pair*>(out + pos0) = Pair{o[0], o[1]};
+        } else {
+            out[pos0] = o[0];
+            if (pos0 + 1 < ncwz) out[pos0 + 1] = o[1];
         }
     }
-    const float o = filler ? __builtin_inff() : val;
-    const size_t oi = (size_t)blk * ncwz + pos;
-    if (a.out_f16) static_cast<__half*>(a.out)[oi] = __float2half(o);
-    else static_cast<float*>(a.out)[oi] = o;
 }
 
 // Transmit side: bit selection + interleaving + concatenation (NRLDPCEncoder.m:168-256) as one gather.
 // Output bit x of code block r is f(x) = e(i*E/Qm + j) with i = x mod Qm, j = x div Qm (:219-223), and
 // e(k) is the (k mod P)-th non-filler position of the circular buffer counted from k_0 (:186-195).
+constexpr int RM_V = 4; // consecutive output bits (bytes) per thread: one dword store
+
 __global__ __launch_bounds__(256) void nrldpc_rate_match_kernel(const TxRmArgs a) {
     const int blk = blockIdx.y;
     const int tb = blk / a.C, r = blk - tb * a.C;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * RM_V;
     const int E = a.E[r];
-    if (x >= E) return;
+    if (x0 >= E) return;
     const int rows = E / a.Qm;
-    const int k = (x % a.Qm) * rows + x / a.Qm;
     const int lo_f = a.Kp - 2 * a.Z > 0 ? a.Kp - 2 * a.Z : 0, hi_f = a.K - 2 * a.Z;
     const int f_hi = hi_f < a.N_cb ? hi_f : a.N_cb;
     const int F = f_hi > lo_f ? f_hi - lo_f : 0;
     const int P = a.N_cb - F;
     auto nf = [&](int p) { int c = p - lo_f; c = c < 0 ? 0 : (c > F ? F : c); return p - c; };
-    int q = (k % P) + nf(a.k0);
-    if (q >= P) q -= P;
-    const int pos = (q < lo_f) ? q : q + F; // q-th non-filler position
-    const int ncwz = 2 * a.Z + a.N;
-    a.g[(size_t)tb * a.G + a.off[r] + x] = a.cw[(size_t)blk * ncwz + 2 * a.Z + pos] & 1u;
+    const int nfk0 = nf(a.k0);
+    const uint8_t* cw = a.cw + (size_t)blk * (2 * a.Z + a.N) + 2 * a.Z;
+    int jx = x0 / a.Qm, i = x0 - jx * a.Qm; // x = jx*Qm + i  <->  k = i*rows + jx
+    uint32_t word = 0;
+#pragma unroll
+    for (int t = 0; t < RM_V; ++t) {
+        uint32_t bit = 0;
+        if (x0 + t < E) {
+            const int k = i * rows + jx;
+            int q = (k < P ? k : k % P) + nfk0; // repetition (E > P) wraps around the buffer
+            if (q >= P) q -= P;
+            const int pos = (q < lo_f) ? q : q + F; // q-th non-filler position
+            bit = cw[pos] & 1u;
+        }
+        word |= bit << (8 * t);
+        if (++i == a.Qm) { i = 0; ++jx; }
+    }
+    uint8_t* g = a.g + (size_t)tb * a.G + a.off[r] + x0;
+    if ((reinterpret_cast<uintptr_t>(g) & 3) == 0 && x0 + RM_V <= E) {
+        *reinterpret_cast<uint32_t*>(g) = word;
+    } else {
+        for (int t = 0; t < RM_V && x0 + t < E; ++t) g[t] = (uint8_t)(word >> (8 * t));
+    }
 }
 
 hipError_t launch_rate_match(const TxRmArgs& a, hipStream_t stream) {
     int emax = 0;
     for (int r = 0; r < a.C; ++r) emax = a.E[r] > emax ? a.E[r] : emax;
     if (emax == 0) return hipSuccess;
-    dim3 grid((emax + 255) / 256, a.n_tb * a.C);
+    const int per_block = 256 * RM_V;
+    dim3 grid((emax + per_block - 1) / per_block, a.n_tb * a.C);
     hipLaunchKernelGGL(nrldpc_rate_match_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_rate_recover(const RmArgs& a, hipStream_t stream) {
     const int ncwz = 2 * a.Z + a.N;
-    dim3 grid((ncwz + 255) / 256, a.n_tb * a.C);
-    hipLaunchKernelGGL(nrldpc_rate_recover_kernel, grid, dim3(256), 0, stream, a);
+    const int per_block = 4 * RR_TILE;
+    dim3 grid((ncwz + per_block - 1) / per_block, a.n_tb * a.C);
+    if (a.out_f16) hipLaunchKernelGGL(nrldpc_rate_recover_kernel<__half>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(nrldpc_rate_recover_kernel<float>, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 CASES = [dict(BG=2, A=100, G=300, Q_m=2), dict(BG=2, A=100, G=3000, Q_m=6, rv_id=2),
          dict(BG=1, A=5000, G=6000, Q_m=4, rv_id=3), dict(BG=1, A=20016, G=60000, Q_m=8, N_L=2, rv_id=1),
          dict(BG=2, A=3842, G=11526, Q_m=2, I_LBRM=1, TBS_LBRM=6000, rv_id=2), dict(BG=1, A=8424, G=25272, Q_m=2),
-         dict(BG=2, A=500, G=5004, Q_m=6)]
+         dict(BG=2, A=500, G=5004, Q_m=6), dict(BG=1, A=50040, G=120000, Q_m=4),  # C = 6: waves loop over code blocks
+         dict(BG=2, A=101, G=300, Q_m=2), dict(BG=1, A=20019, G=40002, Q_m=2, rv_id=1)]  # odd sizes: unaligned rows
 
 
 @pytest.mark.parametrize("kw", CASES)
