@@ -16,7 +16,7 @@ OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_capi.hip"]
 Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
 Z64_PAIRS = [(bg, z) for bg in (1, 2) for z in (64, 128, 192, 256, 320, 384)]  # keep in sync with NRLDPC_Z64_LIST
-HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h"]
+HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_wave.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

@@ -60,6 +60,7 @@ struct nrldpc_codec {
     DevBuf<uint8_t> d_col;
     // encoder solve order
     int p0_shift = 0, step_row[3] = {0, 0, 0}, step_col[3] = {0, 0, 0}, step_shift[3] = {0, 0, 0};
+    int step_nk[3] = {0, 0, 0}, step_kcol[3][3] = {}, step_kshift[3][3] = {}; // already-known core blocks in that row
     // host-entry staging
     DevBuf<char> s_llr;
     DevBuf<uint8_t> s_hard, s_bits;
@@ -105,6 +106,15 @@ bool derive_encoder_order(nrldpc_codec* h) {
             }
             if (nunk == 1) {
                 h->step_row[st] = i; h->step_col[st] = unk; h->step_shift[st] = ush;
+                int nk = 0;
+                for (int e = g.row_ptr[i]; e < g.row_ptr[i + 1]; ++e) {
+                    const int c = g.col[e] - kb;
+                    if (c >= 0 && c < 4 && c != unk) {
+                        if (nk == 3) return false;
+                        h->step_kcol[st][nk] = c; h->step_kshift[st][nk] = s.shift[e]; ++nk;
+                    }
+                }
+                h->step_nk[st] = nk;
                 known[unk] = true; found = true;
             }
         }
@@ -143,9 +153,13 @@ int encode_launch(nrldpc_codec* h, const uint8_t* d_info, int batch, uint8_t* d_
     nrldpc::EncArgs a;
     a.info = d_info; a.cw = d_cw;
     a.row_ptr = h->d_row_ptr.p; a.col = h->d_col.p; a.shift = h->d_shift.p;
-    a.batch = batch; a.Z = s.Z; a.nrows = s.g.nrows; a.ncols = s.g.ncols; a.kb = s.g.kb;
+    a.batch = batch; a.Z = s.Z; a.nrows = s.g.nrows; a.ncols = s.g.ncols; a.kb = s.g.kb; a.nnz = s.g.nnz;
     a.p0_shift = h->p0_shift;
-    for (int i = 0; i < 3; ++i) { a.step_row[i] = h->step_row[i]; a.step_col[i] = h->step_col[i]; a.step_shift[i] = h->step_shift[i]; }
+    for (int i = 0; i < 3; ++i) {
+        a.step_row[i] = h->step_row[i]; a.step_col[i] = h->step_col[i]; a.step_shift[i] = h->step_shift[i];
+        a.step_nk[i] = h->step_nk[i];
+        for (int k = 0; k < 3; ++k) { a.step_kcol[i][k] = h->step_kcol[i][k]; a.step_kshift[i][k] = h->step_kshift[i][k]; }
+    }
     begin_timing(h, stream);
     hipError_t e = nrldpc::launch_encode(a, stream);
     end_timing(h, stream);

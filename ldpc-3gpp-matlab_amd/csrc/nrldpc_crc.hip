@@ -20,59 +20,20 @@
 #include <stdint.h>
 
 #include "nrldpc_kernels.h"
+#include "nrldpc_wave.h"
 
 namespace nrldpc {
 
-__device__ __forceinline__ uint32_t gf2_apply(const uint32_t* M, uint32_t v, int L) {
+// v * M over GF(2), M = 24 columns (zero beyond the CRC length) in kernel-argument memory.  Every lane calls
+// this (wave-uniform control flow): lane b fetches column b once and the 24 columns are then broadcast with
+// v_readlane, so no scalar-load latency sits inside the loop.
+__device__ __forceinline__ uint32_t gf2_apply(const uint32_t* M, uint32_t v) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t mine = M[lane < 24 ? lane : 0];
     uint32_t o = 0;
-    for (int b = 0; b < L; ++b) o ^= ((v >> b) & 1u) ? M[b] : 0u;
+#pragma unroll
+    for (int b = 0; b < 24; ++b) o ^= (0u - ((v >> b) & 1u)) & (uint32_t)__builtin_amdgcn_readlane((int)mine, b);
     return o;
-}
-
-// LDS written by some lanes of a wave is read by other lanes of the same wave: DS instructions of one wave
-// execute in issue order, so only the compiler has to be kept from reordering.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Copy n bytes global -> LDS by one wave with 16-byte loads whatever the source alignment: the LDS copy is
-// placed at the same offset modulo 16 as the source (`base` is 16-byte aligned with 16 bytes of slack), so
-// only the first and last few bytes move one at a time.  Returns the LDS address of byte 0.
-__device__ __forceinline__ uint8_t* stage_row(uint8_t* base, const uint8_t* src, int n) {
-    const int lane = threadIdx.x & 63;
-    const int sh = (int)(reinterpret_cast<uintptr_t>(src) & 15);
-    uint8_t* dst = base + sh;
-    int head = (16 - sh) & 15;
-    head = head < n ? head : n;
-    if (lane < head) dst[lane] = src[lane];
-    const int nv = (n - head) >> 4;
-    const uint4* s4 = reinterpret_cast<const uint4*>(src + head);
-    uint4* d4 = reinterpret_cast<uint4*>(dst + head);
-    for (int i = lane; i < nv; i += 64) d4[i] = s4[i];
-    const int done = head + (nv << 4);
-    if (lane < n - done) dst[done + lane] = src[done + lane];
-    return dst;
-}
-
-// Copy n bytes LDS -> global by one wave with dword stores whatever the two alignments (an unaligned LDS
-// dword is two aligned reads + v_alignbyte; up to 4 bytes past the end are read, never stored), masking
-// every byte to its bit.
-__device__ __forceinline__ void store_row(uint8_t* dst, const uint8_t* src, int n) {
-    const int lane = threadIdx.x & 63;
-    int head = (4 - (int)(reinterpret_cast<uintptr_t>(dst) & 3)) & 3;
-    head = head < n ? head : n;
-    if (lane < head) dst[lane] = src[lane] & 1u;
-    const int nv = (n - head) >> 2;
-    const uintptr_t so = reinterpret_cast<uintptr_t>(src + head);
-    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(so & ~(uintptr_t)3);
-    const uint32_t rot = (uint32_t)(so & 3);
-    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
-    for (int i = lane; i < nv; i += 64)
-        d32[i] = __builtin_amdgcn_alignbyte(s32[i + 1], s32[i], rot) & 0x01010101u;
-    const int done = head + (nv << 2);
-    if (lane < n - done) dst[done + lane] = src[done + lane] & 1u;
 }
 
 // CRC remainder of `len` bits (one per byte, in LDS) by one wave; every lane returns the result.
@@ -84,6 +45,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* bits, int len, const
     const uint32_t top = 1u << (pl.L - 1), mask = (1u << pl.L) - 1u, poly = pl.poly & mask;
     uint32_t reg = 0;
     const int i0 = lane * chunk - pad;
+#pragma unroll 4
     for (int i = i0 < 0 ? 0 : i0; i < i0 + chunk; ++i) {
         const uint32_t fb = ((reg & top) ? 1u : 0u) ^ (bits[i] & 1u);
         reg = (reg << 1) & mask;
@@ -93,7 +55,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* bits, int len, const
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const uint32_t right = __shfl_down(reg, 1 << s, 64);
-        reg = gf2_apply(pl.shiftmat[s], reg, pl.L) ^ right;
+        reg = gf2_apply(pl.shiftmat[s], reg) ^ right;
     }
     return __shfl(reg, 0, 64);
 }
@@ -124,7 +86,7 @@ __global__ __launch_bounds__(256) void nrldpc_crc_check_kernel(const CrcArgs a) 
     __syncthreads();
     if (wave == 0) {
         uint32_t reg = 0;                                    // :336 over b_hat = segment 0 || ... || segment C-1
-        for (int r = 0; r < a.C; ++r) reg = gf2_apply(a.tb.horner, reg, a.tb.L) ^ part[r];
+        for (int r = 0; r < a.C; ++r) reg = gf2_apply(a.tb.horner, reg) ^ part[r];
         int any_cb = 0;
         for (int r = lane; r < a.C; r += 64) any_cb |= cb_fail[r];
         any_cb = __any(any_cb);
@@ -171,8 +133,8 @@ __global__ __launch_bounds__(256) void nrldpc_crc_attach_kernel(const CrcAttachA
     __syncthreads();
     if (wave == (a.C - 1) % nw) { // this wave's row still holds the last code block's share of `a`
         uint32_t reg = 0;         // NRLDPCEncoder.m:80-81 over a = segment 0 || ... || tail
-        for (int r = 0; r + 1 < a.C; ++r) reg = gf2_apply(a.tb.horner, reg, a.tb.L) ^ part[r];
-        reg = gf2_apply(a.tb.horner_tail, reg, a.tb.L) ^ part[a.C - 1];
+        for (int r = 0; r + 1 < a.C; ++r) reg = gf2_apply(a.tb.horner, reg) ^ part[r];
+        reg = gf2_apply(a.tb.horner_tail, reg) ^ part[a.C - 1];
         if (lane < Ltb) row[pay - Ltb + lane] = (uint8_t)((reg >> (Ltb - 1 - lane)) & 1u);
         wave_lds_sync();
         finish(a.C - 1);

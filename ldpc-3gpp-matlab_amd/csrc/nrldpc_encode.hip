@@ -1,20 +1,26 @@
-// nrldpc_encode.hip -- systematic NR LDPC encoder for gfx950.
+// nrldpc_encode.hip -- systematic NR LDPC encoder for gfx950 (SURVEY.md section 8f, row N3).
 //
 // Replaces step(obj.hLDPCEncoder, c) (NRLDPCEncoder.m:158; comm.LDPCEncoder built at :49 from the H of
 // NRLDPC.m:438-440).  The systematic codeword [c; w] with H*[c; w] = 0 is unique, so this kernel is
 // bit-identical to the toolbox encoder by construction; tests check H*cw = 0 and equality with the
 // oracle's encoder.
 //
-// One workgroup per codeword, thread z owns row z of every base-graph row.  Systematic and
-// core-parity bits sit in LDS as bytes [kb+4][Z]; the 4 core rows are solved through the
-// dual-diagonal structure (sum of the four rows isolates p0; the other three blocks follow by
-// substitution in an order the host derives from the table), then each extension row's parity is a
-// plain XOR of rotated reads.  This is not the hot path: Z-wide byte rotations from LDS, ~300 LDS
-// reads per thread.
+// One wave64 per codeword, GF(2) arithmetic on bit-packed columns (32 check rows per XOR):
+//   1. the K systematic bytes are copied to the output;
+//   2. every column the parity equations read is packed with __ballot into a *doubled* bit ring
+//      (bits 0 .. 2Z+31 of the periodic extension), so that the 32 bits  x[(32m + P + t) mod Z], t = 0..31,
+//      of a circulant edge are one unaligned 32-bit window: two LDS words + v_alignbit, for any Z;
+//   3. work items are (base row, word m) pairs spread over the lanes: the 4 core rows give lambda_i, the
+//      dual-diagonal core is solved in the byte domain (4 columns, substitution order derived on the host
+//      from the table), re-packed, and the 42/38 extension rows are plain XORs of windows;
+//   4. parity words are expanded back to one byte per bit on the way out (dword stores when 4 | Z).
+// No workgroup barrier after the table load: waves are independent.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "nrldpc_kernels.h"
+#include "nrldpc_wave.h"
 
 namespace nrldpc {
 
@@ -23,64 +29,176 @@ __device__ __forceinline__ int rotz(int z, int p, int Z) {
     return v >= Z ? v - Z : v;
 }
 
-__global__ __launch_bounds__(384) void nrldpc_encode_kernel(const EncArgs a) {
+struct EncLayout { // LDS words; shared table first, then one region per wave
+    int W, DW, tab, D, lam, PP, xc, wave_words;
+    __host__ __device__ EncLayout(int Z, int kb, int nrows, int nnz) {
+        W = (Z + 31) >> 5;                    // packed words per column
+        DW = 2 * ((2 * Z + 32 + 63) >> 6);    // words of a doubled ring (whole ballots)
+        tab = ((nnz + nrows + 1 + 3) & ~3);   // table: nnz edge words + nrows+1 row pointers
+        D = 0;
+        lam = D + (kb + 4) * DW;
+        PP = lam + 4 * W;
+        xc = PP + (nrows - 4) * W;
+        wave_words = ((xc + Z + 2 + 3) & ~3); // xc: 4*Z bytes + slack
+    }
+};
+
+__global__ __launch_bounds__(256) void nrldpc_encode_kernel(const EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int Z = a.Z, kb = a.kb;
-    uint8_t* x = reinterpret_cast<uint8_t*>(lds);          // [kb+4][Z]
-    uint8_t* lam = x + (size_t)(kb + 4) * Z;               // [4][Z]
-    const int cw = blockIdx.x;
+    const int Z = a.Z, kb = a.kb, nrows = a.nrows;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const EncLayout L(Z, kb, nrows, a.nnz);
+    const int W = L.W, DW = L.DW;
+    uint32_t* tw = reinterpret_cast<uint32_t*>(lds);      // col | shift << 8 per edge
+    uint32_t* rp = tw + a.nnz;                            // row pointers
+    for (int e = threadIdx.x; e < a.nnz; e += blockDim.x) tw[e] = (uint32_t)a.col[e] | ((uint32_t)a.shift[e] << 8);
+    for (int i = threadIdx.x; i <= nrows; i += blockDim.x) rp[i] = a.row_ptr[i];
+    __syncthreads();
+    const int cw = blockIdx.x * nw + wave;
+    if (cw >= a.batch) return;
+    uint32_t* wbase = tw + L.tab + (size_t)wave * L.wave_words;
+    uint32_t* D = wbase + L.D;
+    uint32_t* lamP = wbase + L.lam;
+    uint32_t* PP = wbase + L.PP;
+    uint8_t* xc = reinterpret_cast<uint8_t*>(wbase + L.xc);
     const uint8_t* info = a.info + (size_t)cw * kb * Z;
     uint8_t* out = a.cw + (size_t)cw * a.ncols * Z;
 
-    for (int i = threadIdx.x; i < kb * Z; i += blockDim.x) {
-        const uint8_t b = info[i] & 1;
-        x[i] = b;
-        out[i] = b;
-    }
-    __syncthreads();
-    for (int z = threadIdx.x; z < Z; z += blockDim.x) {
-        uint8_t tot = 0;
-        for (int i = 0; i < 4; ++i) {
-            uint8_t s = 0;
-            for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e)
-                if (a.col[e] < kb) s ^= x[a.col[e] * Z + rotz(z, a.shift[e], Z)];
-            lam[i * Z + z] = s;
-            tot ^= s;
+    // 1. systematic part straight to the output, widest copies both alignments allow
+    {
+        const int n = kb * Z;
+        const uintptr_t al = reinterpret_cast<uintptr_t>(info) | reinterpret_cast<uintptr_t>(out);
+        int done = 0;
+        if ((al & 15) == 0) {
+            for (int i = lane; i < (n >> 4); i += 64) {
+                uint4 v = reinterpret_cast<const uint4*>(info)[i];
+                v.x &= 0x01010101u; v.y &= 0x01010101u; v.z &= 0x01010101u; v.w &= 0x01010101u;
+                reinterpret_cast<uint4*>(out)[i] = v;
+            }
+            done = n & ~15;
+        } else if ((al & 3) == 0) {
+            for (int i = lane; i < (n >> 2); i += 64)
+                reinterpret_cast<uint32_t*>(out)[i] = reinterpret_cast<const uint32_t*>(info)[i] & 0x01010101u;
+            done = n & ~3;
         }
-        x[kb * Z + rotz(z, a.p0_shift, Z)] = tot;
+        for (int i = done + lane; i < n; i += 64) out[i] = info[i] & 1u;
     }
-    __syncthreads();
-    for (int st = 0; st < 3; ++st) {
-        const int i = a.step_row[st], u = a.step_col[st];
-        for (int z = threadIdx.x; z < Z; z += blockDim.x) {
-            uint8_t s = lam[i * Z + z];
-            for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
-                const int c = a.col[e] - kb;
-                if (c >= 0 && c < 4 && c != u) {
-                    bool known = (c == 0);
-                    for (int q = 0; q < st; ++q) known |= (a.step_col[q] == c);
-                    if (known) s ^= x[a.col[e] * Z + rotz(z, a.shift[e], Z)];
+
+    // 2. doubled bit rings of `ncol` byte columns at src -> D[c0 ..]; the byte reads of a batch of ballots are
+    // issued together (global loads for the systematic part, LDS reads for the core parity)
+    const int idx0 = lane % Z, step = 64 % Z;
+    auto pack_b = [&](auto src, int c0, int ncol, auto batch) {
+        constexpr int PB = decltype(batch)::value;
+        for (int c = 0; c < ncol; ++c) {
+            int idx = idx0;
+            for (int w0 = 0; w0 < DW / 2; w0 += PB) {
+                uint8_t b[PB];
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    b[k] = src[c * Z + idx];
+                    idx += step;
+                    if (idx >= Z) idx -= Z;
+                }
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const unsigned long long m = __ballot(b[k] & 1u);
+                    if (w0 + k < DW / 2 && lane < 2) D[(c0 + c) * DW + 2 * (w0 + k) + lane] = (uint32_t)(m >> (32 * lane));
                 }
             }
-            x[(kb + u) * Z + rotz(z, a.step_shift[st], Z)] = s;
         }
-        __syncthreads();
+    };
+    auto pack = [&](auto src, int c0, int ncol) { // batch size: 2 ballots cover Z <= 48, 7 + 6 cover Z = 384
+        if (DW <= 4) pack_b(src, c0, ncol, std::integral_constant<int, 2>{});
+        else pack_b(src, c0, ncol, std::integral_constant<int, 7>{});
+    };
+    // XOR over the edges of base row i with column < col_limit of the 32-bit windows starting at ring bit 32m;
+    // edge words and windows are read in batches so that their LDS latencies overlap
+    constexpr int EB = 5;
+    auto row_word = [&](int i, int m, int col_limit) {
+        uint32_t acc = 0;
+        const int e1 = rp[i + 1];
+        for (int e0 = rp[i]; e0 < e1; e0 += EB) {
+            uint32_t t[EB], lo[EB], hi[EB];
+#pragma unroll
+            for (int k = 0; k < EB; ++k) t[k] = tw[e0 + k < e1 ? e0 + k : e1 - 1];
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const int s = 32 * m + (int)(t[k] >> 8);
+                const uint32_t* d = D + (t[k] & 0xff) * DW + (s >> 5);
+                const bool on = (e0 + k < e1) && (int)(t[k] & 0xff) < col_limit;
+                lo[k] = on ? d[0] : 0u;
+                hi[k] = on ? d[1] : 0u;
+                t[k] = s & 31;
+            }
+#pragma unroll
+            for (int k = 0; k < EB; ++k) acc ^= __builtin_amdgcn_alignbit(hi[k], lo[k], t[k]);
+        }
+        return acc;
+    };
+    auto bit_of = [&](const uint32_t* P, int z) { return (P[z >> 5] >> (z & 31)) & 1u; };
+
+    pack(info, 0, kb);
+    wave_lds_sync();
+    // 3a. lambda_i = systematic part of core row i
+    for (int it = lane; it < 4 * W; it += 64) {
+        const int i = it / W, m = it - i * W;
+        lamP[it] = row_word(i, m, kb);
     }
-    for (int i = threadIdx.x; i < 4 * Z; i += blockDim.x) out[kb * Z + i] = x[kb * Z + i];
-    for (int z = threadIdx.x; z < Z; z += blockDim.x)
-        for (int i = 4; i < a.nrows; ++i) {
-            uint8_t s = 0;
-            for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e)
-                if (a.col[e] < kb + 4) s ^= x[a.col[e] * Z + rotz(z, a.shift[e], Z)];
-            out[(size_t)(kb + i) * Z + z] = s;
+    wave_lds_sync();
+    // 3b. dual-diagonal core in the byte domain: the sum of the four rows isolates p0, the other three
+    // blocks follow by substitution
+    for (int z = lane; z < Z; z += 64) {
+        const uint32_t tot = bit_of(lamP, z) ^ bit_of(lamP + W, z) ^ bit_of(lamP + 2 * W, z) ^ bit_of(lamP + 3 * W, z);
+        xc[rotz(z, a.p0_shift, Z)] = (uint8_t)tot;
+    }
+    wave_lds_sync();
+    for (int st = 0; st < 3; ++st) {
+        const int i = a.step_row[st], u = a.step_col[st], nk = a.step_nk[st];
+        for (int z = lane; z < Z; z += 64) {
+            uint32_t s = bit_of(lamP + i * W, z);
+            for (int k = 0; k < nk; ++k) s ^= xc[a.step_kcol[st][k] * Z + rotz(z, a.step_kshift[st][k], Z)];
+            xc[u * Z + rotz(z, a.step_shift[st], Z)] = (uint8_t)s;
         }
+        wave_lds_sync();
+    }
+    store_row(out + (size_t)kb * Z, xc, 4 * Z);
+    pack(xc, kb, 4);
+    wave_lds_sync();
+    // 3c. extension rows
+    const int next = nrows - 4;
+    for (int it = lane; it < next * W; it += 64) {
+        const int i = it / W, m = it - i * W;
+        PP[it] = row_word(4 + i, m, kb + 4);
+    }
+    wave_lds_sync();
+    // 4. expand the extension parity to bytes
+    uint8_t* ext = out + (size_t)(kb + 4) * Z;
+    if ((Z & 3) == 0 && (reinterpret_cast<uintptr_t>(ext) & 3) == 0) {
+        const int o0 = 4 * lane;
+        int i = o0 / Z, z = o0 - i * Z;
+        const int qi = 256 / Z, qz = 256 - qi * Z;
+        for (int o = o0; o < next * Z; o += 256) {
+            const uint32_t nib = (PP[i * W + (z >> 5)] >> (z & 31)) & 0xFu;
+            *reinterpret_cast<uint32_t*>(ext + o) = (nib * 0x00204081u) & 0x01010101u;
+            i += qi; z += qz;
+            if (z >= Z) { z -= Z; ++i; }
+        }
+    } else {
+        int i = lane / Z, z = lane - i * Z;
+        const int qi = 64 / Z, qz = 64 - qi * Z;
+        for (int o = lane; o < next * Z; o += 64) {
+            ext[o] = (uint8_t)bit_of(PP + i * W, z);
+            i += qi; z += qz;
+            if (z >= Z) { z -= Z; ++i; }
+        }
+    }
 }
 
 hipError_t launch_encode(const EncArgs& a, hipStream_t stream) {
-    int threads = ((a.Z + 63) / 64) * 64;
-    if (threads > 384) threads = 384;
-    const size_t lds = (size_t)(a.kb + 8) * a.Z;
-    hipLaunchKernelGGL(nrldpc_encode_kernel, dim3(a.batch), dim3(threads), lds, stream, a);
+    const EncLayout L(a.Z, a.kb, a.nrows, a.nnz);
+    const int nw = 4; // codewords (waves) per workgroup
+    const size_t lds = 4 * ((size_t)L.tab + (size_t)nw * L.wave_words);
+    hipLaunchKernelGGL(nrldpc_encode_kernel, dim3((a.batch + nw - 1) / nw), dim3(64 * nw), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -33,11 +33,14 @@ struct EncArgs {
     const uint16_t* row_ptr; // device copies of the base graph (CSR) with shifts reduced mod Z
     const uint8_t* col;
     const uint16_t* shift;
-    int32_t batch, Z, nrows, ncols, kb;
+    int32_t batch, Z, nrows, ncols, kb, nnz;
     int32_t p0_shift;        // rot(p0, p0_shift) = lam0+lam1+lam2+lam3
     int32_t step_row[3];     // substitution order for the other three core-parity blocks
     int32_t step_col[3];     // unknown block solved at each step (0..3 relative to kb)
     int32_t step_shift[3];   // shift of the unknown block in that row
+    int32_t step_nk[3];      // core-parity blocks of that row already known at that step ...
+    int32_t step_kcol[3][3]; // ... their columns (0..3 relative to kb) ...
+    int32_t step_kshift[3][3]; // ... and shifts
 };
 
 hipError_t launch_encode(const EncArgs& a, hipStream_t stream);
