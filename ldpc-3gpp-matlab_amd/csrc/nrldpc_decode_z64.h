@@ -35,11 +35,24 @@ constexpr int z64_set_index(int Z) {
     return -1;
 }
 
-// codewords per workgroup: as many as fit 768 threads and the 160 KB of LDS
+// Codewords per workgroup and waves per SIMD the register allocation is sized for (second
+// __launch_bounds__ argument in HIP), per (BG, Z): measured optima on MI355X (tools/exp_z64.sh builds one
+// variant, tools/bench_one.py times it).  What decides: waves resident per CU (BG1 needs ~128 VGPRs -> 4 waves
+// per SIMD = 16 per CU when the codeword's wave count divides into it, else 3; BG2 fits 80 VGPRs -> 6 per
+// SIMD), the 160 KB of LDS, an even spread of a workgroup's waves over the 4 SIMDs, and barrier width.
 template <int BG, int ZC> constexpr int z64_ncwg() {
-    constexpr int cws = (BGT<BG>::KB + 4) * (256 + (ZC + 64) * 4);
-    constexpr int by_lds = (160 * 1024 - 512) / cws;
-    return (768 / ZC) < by_lds ? (768 / ZC) : by_lds;
+#ifdef NRLDPC_Z64_NCWG
+    return NRLDPC_Z64_NCWG;
+#endif
+    if (BG == 1) return ZC == 384 ? 2 : ZC == 320 ? 3 : ZC == 256 ? 2 : ZC == 192 ? 4 : ZC == 128 ? 6 : 2;
+    return ZC == 384 ? 2 : ZC == 320 ? 1 : ZC == 256 ? 3 : ZC == 192 ? 4 : ZC == 128 ? 2 : 4;
+}
+
+template <int BG, int ZC, int NCWG> constexpr int z64_wpe() {
+#ifdef NRLDPC_Z64_WPE
+    return NRLDPC_Z64_WPE;
+#endif
+    return BG == 2 ? 6 : (ZC == 320 || ZC == 256) ? 4 : 3;
 }
 
 template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>()> struct Z64 : BGD<BG> {
@@ -392,7 +405,7 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
 // PLAIN: additionally no early termination and no soft output (the fixed-iteration throughput path): no
 //        per-thread `done` predicate, no extension-bit bookkeeping, no parity pass.
 template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN>
-__global__ __launch_bounds__(NCWG * ZC, BG == 2 ? 6 : 3) void nrldpc_decode_z64_kernel(const DecArgs a) {
+__global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_decode_z64_kernel(const DecArgs a) {
     static_assert(!PLAIN || FULL, "PLAIN implies FULL");
     using G = Z64<BG, ZC, NCWG>;
     extern __shared__ __attribute__((aligned(16))) char lds[];

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Decoder kernel time for every (BG, Z): 25 fixed iterations, all layers, fp16 LLRs resident in HBM, batch
+chosen so that every launch carries about the same number of code bits as the headline (4096 x Z=384).
+Writes gpurun_out/bench_all_z.json; the per-size landscape cited in DESIGN.md."""
+import importlib, json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("ldpc-3gpp-matlab_amd")
+DIMS = {1: (46, 68, 22), 2: (42, 52, 10)}
+ALL_Z = sorted(a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384)
+out = []
+for bg in (1, 2):
+    rows, cols, kb = DIMS[bg]
+    for Z in ALL_Z:
+        B = max(4096, min(262144, (4096 * 384 // Z) // 256 * 256))
+        c = pkg.Codec(bg, Z, max_iter=25, early_term=False, llr_dtype=np.float16)
+        llr = (torch.randn((B, cols * Z), device="cuda") * 2 + 1.5).half()
+        hard = torch.empty((B, kb * Z), device="cuda", dtype=torch.uint8)
+        c.set_timing(True)
+        ms = []
+        for i in range(4):
+            c.decode_dev(llr.data_ptr(), B, hard.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+            ms.append(c.last_kernel_ms())
+        c.close()
+        t = min(ms[1:])
+        rec = {"bg": bg, "Z": Z, "batch": B, "kernel_ms": t, "info_Gbit_s": B * kb * Z / t / 1e6,
+               "edge_updates_per_ns": B * 25 * (316 if bg == 1 else 197) * Z / t / 1e6}
+        out.append(rec)
+        print("BG%d Z=%3d batch %6d: %.3f ms  %.2f Gbit/s info  %.1f edge-updates/ns" % (bg, Z, B, t, rec["info_Gbit_s"], rec["edge_updates_per_ns"]), flush=True)
+        del llr, hard
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_all_z.json"), "w"), indent=1)
