@@ -44,7 +44,7 @@ template <int BG, int ZC> constexpr int z64_ncwg() {
 #ifdef NRLDPC_Z64_NCWG
     return NRLDPC_Z64_NCWG;
 #endif
-    if (BG == 1) return ZC == 384 ? 2 : ZC == 320 ? 3 : ZC == 256 ? 2 : ZC == 192 ? 4 : ZC == 128 ? 6 : 2;
+    if (BG == 1) return ZC == 384 ? 2 : ZC == 320 ? 3 : ZC == 256 ? 2 : ZC == 192 ? 4 : 2;
     return ZC == 384 ? 2 : ZC == 320 ? 1 : ZC == 256 ? 3 : ZC == 192 ? 4 : ZC == 128 ? 2 : 4;
 }
 
@@ -344,6 +344,11 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
         if constexpr (N > 1) l1.finish(st, lds, R, a);
         if constexpr (N > 2) l2.finish(st, lds, R, a);
     }
+    __device__ __forceinline__ void ext(const DecArgs& a, uint32_t& esign_lo, uint32_t& esign_hi) const {
+        l0.ext(a, esign_lo, esign_hi, nullptr);
+        if constexpr (N > 1) l1.ext(a, esign_lo, esign_hi, nullptr);
+        if constexpr (N > 2) l2.ext(a, esign_lo, esign_hi, nullptr);
+    }
     __device__ __forceinline__ void twins(char* lds, uint32_t RA, uint32_t RB, int w) const {
         dispatch_w<0, ZC / 64>(w, [&](auto wc) {
             constexpr int WV = decltype(wc)::value;
@@ -357,10 +362,13 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
 // One iteration: group GI arrives with its early part done; barrier; late part; pass 2; the NEXT group's early
 // part is started before this group's pass 2 so that its LDS latency and min search overlap the barrier wait.
 // Returns (through `next0`) group 0 with its early part done for the following iteration.
-template <int BG, int ZC, int GI>
+// ET: also record the sign of every extension-parity bit's a-posteriori value (the parity pass of the
+// early-termination kernel needs it).
+template <int BG, int ZC, int GI, bool ET = false>
 __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI>& cur, GroupZ64<BG, ZC, 0>& next0, DecState<BG>& st,
                                              char* lds, const uint32_t (&R)[ZC / 64], uint32_t RA, uint32_t RB,
-                                             int w, const DecArgs& a, float cap) {
+                                             int w, const DecArgs& a, float cap, uint32_t& esign_lo,
+                                             uint32_t& esign_hi) {
     constexpr int NG = LayerGroups<BG>::ngroups();
     __syncthreads(); // ends group GI-1 (for GI == 0: the previous iteration / the prologue)
     cur.template loads<true>(lds, R);
@@ -370,13 +378,23 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI>& cur, GroupZ64
         cur.template track<true>(st, cap);
         cur.finish(st, lds, R, a);
         cur.twins(lds, RA, RB, w);
+        if constexpr (ET) {
+            cur.ext(a, esign_lo, esign_hi);
+            // pin the bits here: their only reader is the parity pass, and LLVM otherwise sinks all 42 rows'
+            // sign computations (with lam, m1, M1, M2 of every row kept alive in scratch) down to it
+            asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
+        }
         nxt.template track<false>(st, cap);
-        pipeline_z64<BG, ZC, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap);
+        pipeline_z64<BG, ZC, GI + 1, ET>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
     } else {
         next0.template loads<false>(lds, R);
         cur.template track<true>(st, cap);
         cur.finish(st, lds, R, a);
         cur.twins(lds, RA, RB, w);
+        if constexpr (ET) {
+            cur.ext(a, esign_lo, esign_hi);
+            asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
+        }
         next0.template track<false>(st, cap);
     }
 }
@@ -404,9 +422,12 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
 // FULL : every layer of the base graph is active (n_layers == rows): no per-layer predicates, single mirror twin.
 // PLAIN: additionally no early termination and no soft output (the fixed-iteration throughput path): no
 //        per-thread `done` predicate, no extension-bit bookkeeping, no parity pass.
-template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN>
+// ETP  : FULL with early termination (no soft output): the pipelined iteration of PLAIN plus the sign of every
+//        extension-parity bit, then the parity pass; a finished codeword's waves only keep the barriers.
+template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false>
 __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_decode_z64_kernel(const DecArgs a) {
     static_assert(!PLAIN || FULL, "PLAIN implies FULL");
+    static_assert(!ETP || (FULL && !PLAIN), "ETP implies FULL and excludes PLAIN");
     using G = Z64<BG, ZC, NCWG>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -485,7 +506,7 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
             g0.template track<false>(st, cap);
             for (int it = 1; it <= a.max_iter; ++it) {
                 GroupZ64<BG, ZC, 0> nx;
-                pipeline_z64<BG, ZC, 0>(g0, nx, st, lds, R, RA, RB, w, a, cap);
+                pipeline_z64<BG, ZC, 0>(g0, nx, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
                 g0 = nx;
             }
         } else {
@@ -496,7 +517,63 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
     }
     bool done = !active;
     int my_iters = a.max_iter;
-    if constexpr (!PLAIN) for (int it = 1; it <= a.max_iter; ++it) {
+    // violated-check vote of one codeword's waves -> flags; returns after the closing barrier
+    auto parity_pass = [&](int it) {
+        if (tid <= G::NCWG) flags[tid] = 0;
+        __syncthreads();
+        if (!done) {
+            // A violated check anywhere settles the answer, so a wave stops reading as soon as one of its
+            // 64 rows has failed (voted after each core row, then every 4 rows; this also bounds the loads in flight):
+            // far from convergence the pass costs ~19 LDS reads per thread instead of all 274.
+            uint32_t bad = 0;
+            bool stop = false; // wave-uniform
+            static_for<G::ROWS>([&](auto lc) {
+                constexpr int L = decltype(lc)::value;
+                if (!stop && L < launder(a.n_layers)) {
+                    bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                    if constexpr (L < 4 || (L % 4) == 3) stop = __any((int)bad) != 0;
+                }
+            });
+            if (bad) { flags[cwl] = 1; flags[G::NCWG] = 1; }
+        }
+        __syncthreads();
+        // readfirstlane: the flags are wave-uniform by construction, and `done` has to be *provably* so --
+        // as a divergent predicate it wraps the whole iteration in exec-mask control flow with phi copies
+        // of all 80 state registers (measured: 168 VGPRs + 234 spills instead of 129 and none)
+        const int mine = __builtin_amdgcn_readfirstlane(flags[cwl]);
+        const int any = __builtin_amdgcn_readfirstlane(flags[G::NCWG]);
+        if (!done && mine == 0) { done = true; my_iters = it; }
+        return any == 0; // every codeword of the workgroup has converged
+    };
+    if constexpr (ETP) {
+        // Two loops, so that everything live in the decoding loop is unconditional (as in PLAIN): a wave
+        // whose codeword has converged (or does not exist) drops into the second loop and only keeps the
+        // barrier count of its workgroup until every codeword of it is done.
+        const float cap = 127.49f / a.alpha;
+        int it = 1;
+        bool all_done = false;
+        if (active) {
+            GroupZ64<BG, ZC, 0> g0;
+            g0.template loads<false>(lds, R);
+            g0.template track<false>(st, cap);
+            for (; it <= a.max_iter; ++it) {
+                esign_lo = 0; esign_hi = 0;
+                GroupZ64<BG, ZC, 0> nx;
+                pipeline_z64<BG, ZC, 0, true>(g0, nx, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+                g0 = nx;
+                all_done = parity_pass(it);
+                if (all_done || done) { ++it; break; }
+            }
+        }
+        if (!all_done) {
+            done = true;
+            for (; it <= a.max_iter; ++it) {
+                for (int g = 0; g < LayerGroups<BG>::ngroups(); ++g) __syncthreads();
+                if (parity_pass(it)) break;
+            }
+        }
+    }
+    if constexpr (!PLAIN && !ETP) for (int it = 1; it <= a.max_iter; ++it) {
         if (!done) { esign_lo = 0; esign_hi = 0; }
         static_for<G::ROWS>([&](auto lc) {
             constexpr int L = decltype(lc)::value;
@@ -528,21 +605,7 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
                 }
             }
         });
-        if constexpr (!PLAIN) if (a.early_term) {
-            if (tid <= G::NCWG) flags[tid] = 0;
-            __syncthreads();
-            if (!done) {
-                uint32_t bad = 0;
-                static_for<G::ROWS>([&](auto lc) {
-                    constexpr int L = decltype(lc)::value;
-                    if (L < launder(a.n_layers)) bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
-                });
-                if (bad) { flags[cwl] = 1; flags[G::NCWG] = 1; }
-            }
-            __syncthreads();
-            if (!done && flags[cwl] == 0) { done = true; my_iters = it; }
-            if (flags[G::NCWG] == 0) break;
-        }
+        if (a.early_term && parity_pass(it)) break;
     }
 
     if (active) {
@@ -558,9 +621,9 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
     }
 }
 
-template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN> static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
+template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false> static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
     using G = Z64<BG, ZC, NCWG>;
-    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL, PLAIN>;
+    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL, PLAIN, ETP>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {}; // per device: raising the dynamic-LDS limit is a slow host call, do it once
@@ -578,7 +641,8 @@ template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN> static hipError_t lau
 
 template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
     if (a.n_layers != BGD<BG>::ROWS) return launch_z64f<BG, ZC, NCWG, false, false>(a, s);
-    if (a.early_term || a.app) return launch_z64f<BG, ZC, NCWG, true, false>(a, s);
+    if (a.app) return launch_z64f<BG, ZC, NCWG, true, false>(a, s);
+    if (a.early_term) return launch_z64f<BG, ZC, NCWG, true, false, true>(a, s);
     return launch_z64f<BG, ZC, NCWG, true, true>(a, s);
 }
 
