@@ -196,10 +196,21 @@ __global__ __launch_bounds__(768, BG == 2 ? 6 : 3) void nrldpc_decode_kernel(con
             if (tid <= a.ncw) flags[tid] = 0; // flags[ncw] = "some codeword of this workgroup still fails"
             __syncthreads();
             if (!done) {
+                // One violated check settles a codeword's answer.  A lane that has found one publishes it at
+                // once; at every vote point (each core row, then every 4 rows) a lane whose codeword is already
+                // flagged -- by itself or by any other wave -- has nothing left to learn, and the wave stops
+                // reading when that holds for all its lanes.  Far from convergence: ~19 LDS reads instead of all.
                 uint32_t bad = 0;
+                bool stop = false; // wave-uniform
                 static_for<G::ROWS>([&](auto lc) {
                     constexpr int L = decltype(lc)::value;
-                    if (L < launder(a.n_layers)) bad |= row_parity<BG, L>(lds, zb, a, rot, esign_lo, esign_hi);
+                    if (!stop && L < launder(a.n_layers)) {
+                        bad |= row_parity<BG, L>(lds, zb, a, rot, esign_lo, esign_hi);
+                        if constexpr (L < 4 || (L % 4) == 3) {
+                            if (bad) { flags[cwl] = 1; flags[a.ncw] = 1; }
+                            stop = __all((int)(bad | (uint32_t)__atomic_load_n(&flags[cwl], __ATOMIC_RELAXED))) != 0;
+                        }
+                    }
                 });
                 if (bad) { flags[cwl] = 1; flags[a.ncw] = 1; }
             }
