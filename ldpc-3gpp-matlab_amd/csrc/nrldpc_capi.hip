@@ -5,11 +5,16 @@
 // every decode/encode is a HIP kernel launch, and any HIP failure is reported as NRLDPC_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nrldpc.h"
@@ -47,6 +52,86 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// Pinned host memory for the host-pointer entry points (DMA at PCIe rate; pageable memory is not).
+struct PinBuf {
+    char* p = nullptr;
+    size_t n = 0;
+    hipError_t reserve(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault);
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
+// A few persistent host threads that move (and, for MATLAB doubles, narrow) the caller's pageable arrays
+// into / out of the pinned staging buffers: one core does not keep up with PCIe.
+class HostPool {
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    std::function<void(int, int)> job_;
+    unsigned gen_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+
+public:
+    explicit HostPool(int n) {
+        for (int i = 0; i < n; ++i)
+            th_.emplace_back([this, i, n] {
+                unsigned seen = 0;
+                for (;;) {
+                    std::function<void(int, int)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(m_);
+                        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                        if (stop_) return;
+                        seen = gen_;
+                        f = job_;
+                    }
+                    f(i, n);
+                    {
+                        std::lock_guard<std::mutex> lk(m_);
+                        if (--pending_ == 0) cv_done_.notify_all();
+                    }
+                }
+            });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // f(worker, nworkers) on every worker; returns when all are done
+    void run(std::function<void(int, int)> f) {
+        std::unique_lock<std::mutex> lk(m_);
+        job_ = std::move(f);
+        pending_ = (int)th_.size();
+        ++gen_;
+        cv_.notify_all();
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+    }
+    // dst[i] = src[i] for n bytes, or float(dst) = double(src) for n elements when narrow
+    void move(void* dst, const void* src, size_t n, bool narrow) {
+        run([=](int w, int nw) {
+            const size_t per = ((n + nw - 1) / nw + 63) & ~(size_t)63, lo = std::min(n, per * w), hi = std::min(n, lo + per);
+            if (narrow) {
+                const double* d = static_cast<const double*>(src);
+                float* o = static_cast<float*>(dst);
+                for (size_t i = lo; i < hi; ++i) o[i] = (float)d[i];
+            } else if (hi > lo) {
+                memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, hi - lo);
+            }
+        });
+    }
+};
+
 } // namespace
 
 struct nrldpc_codec {
@@ -67,6 +152,11 @@ struct nrldpc_codec {
     DevBuf<int32_t> s_iters;
     DevBuf<float> s_app;
     std::vector<float> h_narrow;
+    // pipelined host path (large batches): two pinned slots, two streams, copy threads
+    PinBuf pin_in[2], pin_out[2], pin_it[2];
+    hipStream_t xs[2] = {nullptr, nullptr};
+    hipEvent_t xdone[2] = {nullptr, nullptr};
+    HostPool* pool = nullptr;
     // timing
     bool timing = false, have_time = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -254,6 +344,12 @@ void nrldpc_destroy(nrldpc_handle h) {
     h->s_llr.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int i = 0; i < 2; ++i) {
+        h->pin_in[i].release(); h->pin_out[i].release(); h->pin_it[i].release();
+        if (h->xs[i]) (void)hipStreamDestroy(h->xs[i]);
+        if (h->xdone[i]) (void)hipEventDestroy(h->xdone[i]);
+    }
+    delete h->pool;
     delete h;
 }
 
@@ -300,19 +396,68 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     const nrldpc::Schedule& s = h->sched;
     const size_t ncw = (size_t)s.g.ncols * s.Z, K = (size_t)s.g.kb * s.Z;
     const size_t cap = (h->cfg.max_batch > batch) ? (size_t)h->cfg.max_batch : (size_t)batch;
-    const void* src = llr;
-    size_t eb = llr_elem_bytes(h->cfg.llr_dtype);
-    if (h->cfg.llr_dtype == NRLDPC_LLR_F64) { // MATLAB doubles: narrow on the host (halves PCIe bytes)
-        h->h_narrow.resize((size_t)batch * ncw);
-        const double* d = static_cast<const double*>(llr);
-        for (size_t i = 0; i < (size_t)batch * ncw; ++i) h->h_narrow[i] = (float)d[i];
-        src = h->h_narrow.data();
-        eb = 4;
-    }
+    const bool f64 = h->cfg.llr_dtype == NRLDPC_LLR_F64;
+    const size_t eb = llr_elem_bytes(h->cfg.llr_dtype); // on the device (MATLAB doubles are narrowed to f32 on the host)
     HIP_TRY(h->s_llr.reserve(cap * ncw * eb));
     HIP_TRY(h->s_hard.reserve(cap * K));
     if (iters_out) HIP_TRY(h->s_iters.reserve(cap));
     if (app_out) HIP_TRY(h->s_app.reserve(cap * ncw));
+
+    // Large batches: chunks of ~32 MB (NRLDPC_HOST_CHUNK_MB; NRLDPC_HOST_THREADS copy threads, default 8;
+    // NRLDPC_HOST_PIPELINE=0 disables) flow caller array -> pinned slot (copy threads) -> H2D -> decode -> D2H ->
+    // pinned slot -> caller array on two alternating streams, so that host copies, both DMA directions and
+    // the kernels of neighbouring chunks overlap.  Same kernels, same results as one launch.
+    const size_t in_bytes = (size_t)batch * ncw * eb;
+    static const int env_chunk_mb = getenv("NRLDPC_HOST_CHUNK_MB") ? atoi(getenv("NRLDPC_HOST_CHUNK_MB")) : 32;
+    static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 8;
+    static const int env_pipe = getenv("NRLDPC_HOST_PIPELINE") ? atoi(getenv("NRLDPC_HOST_PIPELINE")) : 1;
+    if (env_pipe && in_bytes >= ((size_t)32 << 20) && !app_out && !h->timing) {
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, ((size_t)std::max(1, env_chunk_mb) << 20) / (ncw * eb)));
+        if (!h->pool) {
+            const unsigned hc = std::thread::hardware_concurrency();
+            h->pool = new (std::nothrow) HostPool((int)std::max(1u, std::min((unsigned)std::max(1, env_threads), hc ? hc / 2 : 4u)));
+            if (!h->pool) return fail(NRLDPC_ERR_NOMEM, "host thread pool");
+        }
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(h->pin_in[i].reserve((size_t)chunk * ncw * eb));
+            HIP_TRY(h->pin_out[i].reserve((size_t)chunk * K));
+            if (iters_out) HIP_TRY(h->pin_it[i].reserve((size_t)chunk * 4));
+            if (!h->xs[i]) HIP_TRY(hipStreamCreateWithFlags(&h->xs[i], hipStreamNonBlocking));
+            if (!h->xdone[i]) HIP_TRY(hipEventCreateWithFlags(&h->xdone[i], hipEventDisableTiming));
+        }
+        const int nchunks = (batch + chunk - 1) / chunk;
+        auto drain = [&](int k) -> int { // results of chunk k: pinned slot -> caller arrays
+            const int sl = k & 1, c0 = k * chunk, n = std::min(chunk, batch - c0);
+            HIP_TRY(hipEventSynchronize(h->xdone[sl]));
+            h->pool->move(hard + (size_t)c0 * K, h->pin_out[sl].p, (size_t)n * K, false);
+            if (iters_out) memcpy(iters_out + c0, h->pin_it[sl].p, (size_t)n * 4);
+            return NRLDPC_OK;
+        };
+        for (int k = 0; k < nchunks; ++k) {
+            const int sl = k & 1, c0 = k * chunk, n = std::min(chunk, batch - c0);
+            if (k >= 2) { int rc = drain(k - 2); if (rc) return rc; } // also frees pin_in[sl]
+            const size_t off = (size_t)c0 * ncw;
+            if (f64) h->pool->move(h->pin_in[sl].p, static_cast<const double*>(llr) + off, (size_t)n * ncw, true);
+            else h->pool->move(h->pin_in[sl].p, static_cast<const char*>(llr) + off * eb, (size_t)n * ncw * eb, false);
+            char* d_in = h->s_llr.p + off * eb;
+            HIP_TRY(hipMemcpyAsync(d_in, h->pin_in[sl].p, (size_t)n * ncw * eb, hipMemcpyHostToDevice, h->xs[sl]));
+            int rc = decode_launch(h, d_in, n, h->s_hard.p + (size_t)c0 * K, iters_out ? h->s_iters.p + c0 : nullptr, nullptr, h->xs[sl]);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(h->pin_out[sl].p, h->s_hard.p + (size_t)c0 * K, (size_t)n * K, hipMemcpyDeviceToHost, h->xs[sl]));
+            if (iters_out) HIP_TRY(hipMemcpyAsync(h->pin_it[sl].p, h->s_iters.p + c0, (size_t)n * 4, hipMemcpyDeviceToHost, h->xs[sl]));
+            HIP_TRY(hipEventRecord(h->xdone[sl], h->xs[sl]));
+        }
+        for (int k = std::max(0, nchunks - 2); k < nchunks; ++k) { int rc = drain(k); if (rc) return rc; }
+        return NRLDPC_OK;
+    }
+
+    const void* src = llr;
+    if (f64) { // MATLAB doubles: narrow on the host (halves PCIe bytes)
+        h->h_narrow.resize((size_t)batch * ncw);
+        const double* d = static_cast<const double*>(llr);
+        for (size_t i = 0; i < (size_t)batch * ncw; ++i) h->h_narrow[i] = (float)d[i];
+        src = h->h_narrow.data();
+    }
     HIP_TRY(hipMemcpyAsync(h->s_llr.p, src, (size_t)batch * ncw * eb, hipMemcpyHostToDevice, nullptr));
     // F64 was narrowed to f32 above; the kernel sees f32 in that case.
     int rc = decode_launch(h, h->s_llr.p, batch, h->s_hard.p, iters_out ? h->s_iters.p : nullptr,

@@ -85,3 +85,28 @@ def test_host_and_device_entry_points_agree(pkg, orc):
     torch.cuda.synchronize()
     c.close()
     assert (d_h.cpu().numpy() == h1).all() and (d_it.cpu().numpy() == it1).all()
+
+
+@pytest.mark.parametrize("dt,B", [(np.float64, 1237), (np.float32, 1001), (np.float16, 2049)])
+def test_pipelined_host_path_equals_one_device_launch(pkg, orc, dt, B):
+    """Batches above 32 MB take the chunked, double-buffered host path of nrldpc_decode (pinned staging, copy
+    threads, two streams); it must return exactly what one device launch on the same LLRs returns, for a
+    batch that is not a multiple of the chunk size and for every boundary dtype (MATLAB doubles included)."""
+    import torch
+    rng = np.random.default_rng(B)
+    c = pkg.Codec(1, 384, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dt)
+    info = rng.integers(0, 2, (B, c.K), dtype=np.uint8)
+    llr = awgn_llr(rng, c.encode(info), -0.3, dt, 384)
+    assert llr.nbytes >= (32 << 20) * (2 if dt == np.float64 else 1)
+    h1, it1 = c.decode(llr, want_iters=True)
+    h2 = c.decode(llr)                                       # second call reuses the pinned slots
+    dev_dt = np.float32 if dt == np.float64 else dt
+    cd = pkg.Codec(1, 384, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dev_dt)
+    d_llr = torch.from_numpy(llr.astype(dev_dt)).cuda()
+    d_h = torch.empty((B, c.K), dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(B, dtype=torch.int32, device="cuda")
+    cd.decode_dev(d_llr.data_ptr(), B, d_h.data_ptr(), d_it.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    c.close(); cd.close()
+    assert (d_h.cpu().numpy() == h1).all() and (d_it.cpu().numpy() == it1).all() and (h2 == h1).all()
+    assert (h1 != info).any(1).mean() < 0.05 and it1.min() < 12
