@@ -403,7 +403,7 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     if (iters_out) HIP_TRY(h->s_iters.reserve(cap));
     if (app_out) HIP_TRY(h->s_app.reserve(cap * ncw));
 
-    // Large batches: chunks of ~32 MB (NRLDPC_HOST_CHUNK_MB; NRLDPC_HOST_THREADS copy threads, default 8;
+    // Batches above 8 MB: chunks of up to ~32 MB (NRLDPC_HOST_CHUNK_MB; NRLDPC_HOST_THREADS copy threads, default 8;
     // NRLDPC_HOST_PIPELINE=0 disables) flow caller array -> pinned slot (copy threads) -> H2D -> decode -> D2H ->
     // pinned slot -> caller array on two alternating streams, so that host copies, both DMA directions and
     // the kernels of neighbouring chunks overlap.  Same kernels, same results as one launch.
@@ -411,8 +411,9 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     static const int env_chunk_mb = getenv("NRLDPC_HOST_CHUNK_MB") ? atoi(getenv("NRLDPC_HOST_CHUNK_MB")) : 32;
     static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 8;
     static const int env_pipe = getenv("NRLDPC_HOST_PIPELINE") ? atoi(getenv("NRLDPC_HOST_PIPELINE")) : 1;
-    if (env_pipe && in_bytes >= ((size_t)32 << 20) && !app_out && !h->timing) {
-        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, ((size_t)std::max(1, env_chunk_mb) << 20) / (ncw * eb)));
+    if (env_pipe && in_bytes >= ((size_t)8 << 20) && !app_out && !h->timing) {
+        const size_t chunk_bytes = std::min<size_t>((size_t)std::max(1, env_chunk_mb) << 20, in_bytes / 4); // >= 4 chunks
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, chunk_bytes / (ncw * eb)));
         if (!h->pool) {
             const unsigned hc = std::thread::hardware_concurrency();
             h->pool = new (std::nothrow) HostPool((int)std::max(1u, std::min((unsigned)std::max(1, env_threads), hc ? hc / 2 : 4u)));
