@@ -82,6 +82,16 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
 int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t* d_hard,
                       int32_t* d_iters_out, float* d_app_out, void* stream);
 
+/* Mixed batches: n configurations (handles of one device that may differ in base graph, lifting size, layer
+ * count, iteration cap, ...) decoded with one launch per base graph and LLR type instead of n launches --
+ * a small bucket alone is a one-workgroup kernel that leaves the GPU idle.  For i < n: batch[i] codewords at
+ * d_llr[i] (dtype of h[i]) -> d_hard[i], iteration counts to d_iters[i] when d_iters and d_iters[i] are
+ * non-null.  Results are those of n nrldpc_decode_dev calls.  Tables are staged in h[0]; asynchronous on
+ * `stream`.  (The reference decodes one code block per step(), NRLDPCDecoder.m:257-266; a receiver serving many
+ * users holds exactly such a mix of (BG, Z_c).) */
+int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* h, const void* const* d_llr, const int32_t* batch,
+                            uint8_t* const* d_hard, int32_t* const* d_iters, void* stream);
+
 /* Systematic encode.  info: [batch][K] bytes {0,1}; cw: [batch][ncols*Z] bytes {0,1} = [info;parity]
  * with H*cw = 0 (NRLDPCEncoder.m:158). */
 int nrldpc_encode(nrldpc_handle h, const uint8_t* info, int32_t batch, uint8_t* cw);

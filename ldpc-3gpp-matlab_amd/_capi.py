@@ -58,7 +58,7 @@ def tb_params(p):
 
 
 EXPORTS = ["nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
-           "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
+           "nrldpc_decode_multi_dev", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version"]
 
@@ -96,6 +96,7 @@ def load():
     L.nrldpc_get_dims.argtypes = [vp, C.POINTER(Dims)]
     L.nrldpc_decode.argtypes = [vp, vp, i32, vp, vp, vp]
     L.nrldpc_decode_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.nrldpc_decode_multi_dev.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), vp]
     L.nrldpc_encode.argtypes = [vp, vp, i32, vp]
     L.nrldpc_encode_dev.argtypes = [vp, vp, i32, vp, vp]
     L.nrldpc_rate_recover_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, i32, vp]
@@ -205,6 +206,19 @@ class Codec:
         ms = C.c_float()
         check(self._lib.nrldpc_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+
+def decode_multi_dev(codecs, d_llr, batch, d_hard, d_iters=None, stream=0):
+    """One launch per base graph and LLR type for a mix of configurations (nrldpc_decode_multi_dev):
+    codecs[i] decodes batch[i] codewords at device address d_llr[i] into d_hard[i] (and d_iters[i])."""
+    n = len(codecs)
+    vp = C.c_void_p
+    hs = (vp * n)(*[c._h for c in codecs])
+    llr = (vp * n)(*[int(x) for x in d_llr])
+    hard = (vp * n)(*[int(x) for x in d_hard])
+    its = (vp * n)(*[int(x) if x else None for x in d_iters]) if d_iters is not None else None
+    bt = (C.c_int32 * n)(*[int(b) for b in batch])
+    check(load().nrldpc_decode_multi_dev(n, hs, llr, bt, hard, its, C.c_void_p(stream)))
 
 
 def rate_recover_dev(p, d_g_tilde, n_tb, d_harq, d_cw_llr, out_dtype=LLR_F32, stream=0):

@@ -152,6 +152,7 @@ struct nrldpc_codec {
     DevBuf<int32_t> s_iters;
     DevBuf<float> s_app;
     std::vector<float> h_narrow;
+    DevBuf<char> multi_tab; // argument blocks + workgroup prefix tables of nrldpc_decode_multi_dev
     // pipelined host path (large batches): two pinned slots, two streams, copy threads
     PinBuf pin_in[2], pin_out[2], pin_it[2];
     hipStream_t xs[2] = {nullptr, nullptr};
@@ -220,10 +221,11 @@ void end_timing(nrldpc_codec* h, hipStream_t s) {
     if (h->timing) { (void)hipEventRecord(h->ev1, s); h->have_time = true; }
 }
 
-int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters, float* d_app,
-                  hipStream_t stream) {
+nrldpc::DecArgs make_dec_args(const nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters,
+                              float* d_app) {
     const nrldpc::Schedule& s = h->sched;
     nrldpc::DecArgs a;
+    memset(&a, 0, sizeof a);
     a.llr = d_llr; a.hard = d_hard; a.iters = d_iters; a.app = d_app;
     a.rot = h->d_rot.p;
     a.batch = batch; a.Z = s.Z; a.n_layers = s.n_layers; a.max_iter = h->cfg.max_iter; a.ncw = s.ncw; a.sbw = s.sbw;
@@ -231,6 +233,13 @@ int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard
     a.need_ext = (a.early_term || d_app) ? 1 : 0;
     a.llr_kind = (h->cfg.llr_dtype == NRLDPC_LLR_F16) ? NRLDPC_K_F16 : NRLDPC_K_F32;
     a.alpha = h->alpha; a.scale = (float)h->scale; a.inv_scale = 1.0f / (float)h->scale;
+    return a;
+}
+
+int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters, float* d_app,
+                  hipStream_t stream) {
+    const nrldpc::Schedule& s = h->sched;
+    const nrldpc::DecArgs a = make_dec_args(h, d_llr, batch, d_hard, d_iters, d_app);
     begin_timing(h, stream);
     hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, stream);
     end_timing(h, stream);
@@ -342,6 +351,7 @@ void nrldpc_destroy(nrldpc_handle h) {
     h->d_rot.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
     h->s_llr.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
+    h->multi_tab.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int i = 0; i < 2; ++i) {
@@ -385,6 +395,64 @@ int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t
     if (h->cfg.llr_dtype == NRLDPC_LLR_F64) return fail(NRLDPC_ERR_ARG, "f64 LLRs are accepted by the host entry point only");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     return decode_launch(h, d_llr, batch, d_hard, d_iters_out, d_app_out, static_cast<hipStream_t>(stream));
+}
+
+int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* const* d_llr, const int32_t* batch,
+                            uint8_t* const* d_hard, int32_t* const* d_iters, void* stream) {
+    if (n < 0) return fail(NRLDPC_ERR_ARG, "negative configuration count");
+    if (n == 0) return NRLDPC_OK;
+    if (!hs || !d_llr || !batch || !d_hard) return fail(NRLDPC_ERR_ARG, "null array");
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) return fail(NRLDPC_ERR_ARG, "null handle");
+        if (batch[i] < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+        if (batch[i] > 0 && (!d_llr[i] || !d_hard[i])) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
+        if (hs[i]->cfg.llr_dtype == NRLDPC_LLR_F64) return fail(NRLDPC_ERR_ARG, "f64 LLRs are accepted by the host entry point only");
+        if (hs[i]->cfg.device_id != hs[0]->cfg.device_id) return fail(NRLDPC_ERR_ARG, "all handles of one call must live on one device");
+    }
+    nrldpc_codec* own = hs[0]; // its scratch holds the tables
+    HIP_TRY(hipSetDevice(own->cfg.device_id));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // one group per (base graph, LLR type): argument blocks, then the workgroup prefix table
+    struct Group { std::vector<nrldpc::DecArgs> args; std::vector<int32_t> start; size_t lds = 0; int grid = 0; };
+    Group g[2][2];
+    for (int i = 0; i < n; ++i) {
+        if (batch[i] == 0) continue;
+        const nrldpc_codec* h = hs[i];
+        const nrldpc::Schedule& s = h->sched;
+        Group& q = g[s.g.bg - 1][h->cfg.llr_dtype == NRLDPC_LLR_F16 ? 1 : 0];
+        q.args.push_back(make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr));
+        q.start.push_back(q.grid);
+        q.grid += (batch[i] + s.ncw - 1) / s.ncw;
+        q.lds = std::max(q.lds, s.lds_bytes);
+    }
+    std::vector<char> host;
+    size_t off[2][2][2];
+    for (int b = 0; b < 2; ++b)
+        for (int d = 0; d < 2; ++d) {
+            Group& q = g[b][d];
+            if (q.args.empty()) continue;
+            q.start.push_back(q.grid);
+            host.resize((host.size() + 15) & ~(size_t)15);
+            off[b][d][0] = host.size();
+            host.insert(host.end(), reinterpret_cast<const char*>(q.args.data()),
+                        reinterpret_cast<const char*>(q.args.data() + q.args.size()));
+            off[b][d][1] = host.size();
+            host.insert(host.end(), reinterpret_cast<const char*>(q.start.data()),
+                        reinterpret_cast<const char*>(q.start.data() + q.start.size()));
+        }
+    if (host.empty()) return NRLDPC_OK;
+    HIP_TRY(own->multi_tab.reserve(host.size()));
+    HIP_TRY(hipMemcpyAsync(own->multi_tab.p, host.data(), host.size(), hipMemcpyHostToDevice, st)); // pageable: staged before return
+    for (int b = 0; b < 2; ++b)
+        for (int d = 0; d < 2; ++d) {
+            const Group& q = g[b][d];
+            if (q.args.empty()) continue;
+            hipError_t e = nrldpc::launch_decode_multi(
+                b + 1, d ? NRLDPC_K_F16 : NRLDPC_K_F32, reinterpret_cast<const nrldpc::DecArgs*>(own->multi_tab.p + off[b][d][0]),
+                reinterpret_cast<const int32_t*>(own->multi_tab.p + off[b][d][1]), (int)q.args.size(), q.grid, q.lds, st);
+            if (e != hipSuccess) return hipfail(e, "multi-configuration decode launch");
+        }
+    return NRLDPC_OK;
 }
 
 int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out) {

@@ -21,6 +21,10 @@ struct DecArgs {
 };
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream);
+// many (Z) configurations of one base graph in one launch of the run-time-Z kernel: d_tab[nb] argument blocks,
+// d_start[nb+1] first workgroup of each configuration (d_start[nb] = grid)
+hipError_t launch_decode_multi(int bg, int llr_kind, const DecArgs* d_tab, const int32_t* d_start, int nb, int grid,
+                               size_t lds_bytes, hipStream_t stream);
 // compile-time-Z specialisations (nrldpc_decode_z64_inst.hip), one per (BG, Z) with Z a multiple of 64
 #define NRLDPC_Z64_LIST(X) X(1, 64) X(1, 128) X(1, 192) X(1, 256) X(1, 320) X(1, 384) X(2, 64) X(2, 128) X(2, 192) X(2, 256) X(2, 320) X(2, 384)
 #define NRLDPC_Z64_DECL(bg, z) hipError_t launch_decode_z64_##bg##_##z(const DecArgs& a, hipStream_t stream);

@@ -110,3 +110,43 @@ def test_pipelined_host_path_equals_one_device_launch(pkg, orc, dt, B):
     c.close(); cd.close()
     assert (d_h.cpu().numpy() == h1).all() and (d_it.cpu().numpy() == it1).all() and (h2 == h1).all()
     assert (h1 != info).any(1).mean() < 0.05 and it1.min() < 12
+
+
+def test_cfg4_one_launch_per_base_graph_equals_one_launch_per_bucket(pkg, orc):
+    """nrldpc_decode_multi_dev: the mixed batch of BASELINE configuration 4 in two launches (one per base graph)
+    must return what 102 separate nrldpc_decode_dev launches return: hard bits and iteration counts, including
+    buckets of one codeword, pruned layer counts and differing iteration caps."""
+    import torch
+    rng = np.random.default_rng(44)
+    draws = [(int(rng.integers(1, 3)), int(rng.choice(ALL_Z))) for _ in range(8192)]
+    buckets = {}
+    for key in draws:
+        buckets[key] = buckets.get(key, 0) + 1
+    buckets[(1, 7)] = 1                                            # a single-codeword bucket
+    codecs, llrs, ns, ref_h, ref_i = [], [], [], [], []
+    s = torch.cuda.current_stream().cuda_stream
+    for k, ((bg, Z), n) in enumerate(sorted(buckets.items())):
+        rows, cols, kb = BG_DIMS[bg]
+        nl = 0 if k % 3 else max(4, rows - (k % 11))               # some pruned layer counts
+        c = pkg.Codec(bg, Z, max_iter=12 + (k % 5), n_layers=nl, early_term=bool(k % 4), llr_dtype=np.float16, alpha=0.625)
+        info = rng.integers(0, 2, (n, kb * Z), dtype=np.uint8)
+        llr = torch.from_numpy(awgn_llr(rng, c.encode(info), 2.0, np.float16, Z)).cuda()
+        h = torch.empty((n, kb * Z), dtype=torch.uint8, device="cuda")
+        it = torch.empty(n, dtype=torch.int32, device="cuda")
+        c.decode_dev(llr.data_ptr(), n, h.data_ptr(), it.data_ptr(), None, s)
+        codecs.append(c); llrs.append(llr); ns.append(n); ref_h.append(h); ref_i.append(it)
+    out_h = [torch.zeros_like(h) for h in ref_h]
+    out_i = [torch.zeros_like(i) for i in ref_i]
+    pkg.decode_multi_dev(codecs, [x.data_ptr() for x in llrs], ns, [x.data_ptr() for x in out_h],
+                         [x.data_ptr() for x in out_i], s)
+    torch.cuda.synchronize()
+    for k in range(len(codecs)):
+        assert (out_h[k] == ref_h[k]).all() and (out_i[k] == ref_i[k]).all(), (k, codecs[k].Z)
+    # no iteration counts requested, and an empty configuration in the middle
+    out2 = [torch.zeros_like(h) for h in ref_h]
+    ns2 = list(ns); ns2[3] = 0
+    pkg.decode_multi_dev(codecs, [x.data_ptr() for x in llrs], ns2, [x.data_ptr() for x in out2], None, s)
+    torch.cuda.synchronize()
+    assert all((out2[k] == ref_h[k]).all() for k in range(len(codecs)) if k != 3) and int(out2[3].sum()) == 0
+    for c in codecs:
+        c.close()

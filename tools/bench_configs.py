@@ -78,17 +78,37 @@ def mixed(B=8192, iters=25):
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) * 1e3
         best = t if best is None else min(best, t)
+    per_bucket = best
+    # the same batch through nrldpc_decode_multi_dev: one launch per base graph
+    ref = [w[2].clone() for w in work]
+    s0 = torch.cuda.current_stream().cuda_stream
+    best = None
+    for _ in range(6):
+        for w in work:
+            w[2].zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pkg.decode_multi_dev([w[0] for w in work], [w[1].data_ptr() for w in work], [w[3] for w in work],
+                             [w[2].data_ptr() for w in work], None, s0)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) * 1e3
+        best = t if best is None else min(best, t)
+    assert all(bool((w[2] == r).all()) for w, r in zip(work, ref)), "multi launch differs from per-bucket launches"
     bits = sum(n * K for _, _, _, n, K in work)
     for w in work:
         w[0].close()
-    rec = {"config": "cfg4 mixed BG1/BG2, Z in {2..384}, batch 8192, one launch per (BG,Z) bucket on 8 HIP streams", "buckets": len(work),
-           "wall_ms_all_launches": best, "info_Gbit_s": bits / best / 1e6, "info_bits": bits}
+    rec = {"config": "cfg4 mixed BG1/BG2, Z in {2..384}, batch 8192, nrldpc_decode_multi_dev (one launch per base graph)",
+           "buckets": len(work), "wall_ms": best, "info_Gbit_s": bits / best / 1e6, "info_bits": bits,
+           "wall_ms_one_launch_per_bucket_8_streams": per_bucket, "info_Gbit_s_one_launch_per_bucket": bits / per_bucket / 1e6}
     print(rec, flush=True)
     return rec
 
 
 def main():
     out = []
+    if "--only-mixed" in sys.argv:
+        mixed()
+        return
     out.append(run("cfg2 BG1 Z=384 R=1/3 25it fixed, batch 4096 (headline)", 1, 384, 4096, 25344, 0, 25, 0, -0.5))
     out.append(run("cfg2 with parity-check early stop (reference semantics)", 1, 384, 4096, 25344, 0, 25, 1, -0.5))
     for R, E, nl, esn0 in (("1/5", 19120, 42, -3.0), ("1/4", 15296, 32, -2.0), ("1/3", 11472, 22, -0.5), ("2/5", 9560, 17, 0.5),
