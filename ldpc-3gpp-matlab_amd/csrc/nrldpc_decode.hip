@@ -159,10 +159,21 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
             });
         }
         {   // extension columns -> int8 registers (thread-private: shift 0, degree 1)
+            // the extension-parity LLR of a pruned row is never used (only soft output echoes it): blocks of 8
+            // rows behind wave-uniform branches keep those columns out of the HBM traffic
             float x[G::NEXT];
-            static_for<G::NEXT>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                x[i] = load_llr<DT>(a.llr, base + (size_t)(G::NC + i) * Z + z);
+            const int next_used = a.app ? G::NEXT : launder(a.n_layers) - 4;
+            static_for<(G::NEXT + 7) / 8>([&](auto bc) {
+                constexpr int i0 = decltype(bc)::value * 8;
+                constexpr int i1 = i0 + 8 < G::NEXT ? i0 + 8 : G::NEXT;
+                if (i0 < next_used) {
+                    static_for<i1 - i0>([&](auto ic) {
+                        constexpr int i = i0 + decltype(ic)::value;
+                        x[i] = load_llr<DT>(a.llr, base + (size_t)(G::NC + i) * Z + z);
+                    });
+                } else {
+                    static_for<i1 - i0>([&](auto ic) { x[i0 + decltype(ic)::value] = 0.0f; });
+                }
             });
             static_for<G::NEXT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;

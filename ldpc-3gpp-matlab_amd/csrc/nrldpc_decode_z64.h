@@ -462,7 +462,42 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
         if (a.app) app_row = a.app + base + z;
         const bool f16 = a.llr_kind == NRLDPC_K_F16;
         char* home = lds + cwbase + G::GUARD + 4 * z; // ring position z of column 0
-        {
+        // Core columns -> LDS.  A quarter of the codeword's threads covers one column with 4 consecutive ring
+        // positions each (8- or 16-byte loads, ds_write_b128), four columns per pass: 7 load instructions per
+        // thread instead of 26 two-byte ones.  Unaligned LLR pointers take the one-position-per-thread path.
+        constexpr int QW = ZC / 4;
+        const int qs = z / QW, qq = z - qs * QW; // column within a pass, quad within the column
+        const bool wide = (reinterpret_cast<uintptr_t>(a.llr) & 15) == 0;
+        if (wide) {
+            constexpr int NP = (G::NC + 3) / 4;
+            float4 x[NP];
+            static_for<NP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int c = 4 * k + qs;
+                x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (4 * k + 3 < G::NC || c < G::NC) {
+                    const size_t i = base + (size_t)c * ZC + 4 * qq;
+                    if (f16) {
+                        const uint2 r = *reinterpret_cast<const uint2*>(static_cast<const __half*>(a.llr) + i);
+                        const __half2 lo = *reinterpret_cast<const __half2*>(&r.x), hi = *reinterpret_cast<const __half2*>(&r.y);
+                        x[k] = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
+                    } else {
+                        x[k] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.llr) + i);
+                    }
+                }
+            });
+            static_for<NP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int c = 4 * k + qs;
+                if (4 * k + 3 < G::NC || c < G::NC) {
+                    const float4 q = make_float4(ingest(x[k].x, a.scale, true), ingest(x[k].y, a.scale, true),
+                                                 ingest(x[k].z, a.scale, true), ingest(x[k].w, a.scale, true));
+                    char* col = lds + cwbase + G::GUARD + c * G::CS;
+                    *reinterpret_cast<float4*>(col + 16 * qq) = q;
+                    if (qq < 16) *reinterpret_cast<float4*>(col + 4 * ZC + 16 * qq) = q; // mirror of block 0
+                }
+            });
+        } else {
             float x[G::NC];
             static_for<G::NC>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
@@ -477,11 +512,22 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
             });
         }
         {
+            // The extension-parity LLR of a pruned row is never used (only soft output echoes it): at R = 8/9
+            // that is 41 of 68 columns of HBM input saved.  Blocks of 8 rows, wave-uniform branches.
             float x[G::NEXT];
-            static_for<G::NEXT>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const size_t gi = base + (size_t)(G::NC + i) * ZC + z;
-                x[i] = f16 ? load_llr<NRLDPC_K_F16>(a.llr, gi) : load_llr<NRLDPC_K_F32>(a.llr, gi);
+            const int next_used = (FULL || a.app) ? G::NEXT : launder(a.n_layers) - 4;
+            static_for<(G::NEXT + 7) / 8>([&](auto bc) {
+                constexpr int i0 = decltype(bc)::value * 8;
+                constexpr int i1 = i0 + 8 < G::NEXT ? i0 + 8 : G::NEXT;
+                if (FULL || i0 < next_used) {
+                    static_for<i1 - i0>([&](auto ic) {
+                        constexpr int i = i0 + decltype(ic)::value;
+                        const size_t gi = base + (size_t)(G::NC + i) * ZC + z;
+                        x[i] = f16 ? load_llr<NRLDPC_K_F16>(a.llr, gi) : load_llr<NRLDPC_K_F32>(a.llr, gi);
+                    });
+                } else {
+                    static_for<i1 - i0>([&](auto ic) { x[i0 + decltype(ic)::value] = 0.0f; });
+                }
             });
             static_for<G::NEXT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -611,13 +657,29 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
     if (active) {
         if (a.iters && z == 0) a.iters[cw] = my_iters;
         uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * ZC);
-        const char* home = lds + cwbase + G::GUARD + 4 * z;
-        static_for<G::NC>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            const float val = *reinterpret_cast<const float*>(home + c * G::CS);
-            if (c < G::KB) hard[(size_t)c * ZC + z] = val < 0.0f ? 1 : 0;
-            if (app_row) app_row[(size_t)c * ZC] = val * a.inv_scale;
-        });
+        if (!app_row && (reinterpret_cast<uintptr_t>(a.hard) & 3) == 0) {
+            // hard decisions, 4 ring positions per thread: one ds_read_b128 and one dword store per column quarter
+            constexpr int QW = ZC / 4;
+            const int qs = z / QW, qq = z - qs * QW;
+            static_for<(G::KB + 3) / 4>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int c = 4 * k + qs;
+                if (4 * k + 3 < G::KB || c < G::KB) {
+                    const float4 v = *reinterpret_cast<const float4*>(lds + cwbase + G::GUARD + c * G::CS + 16 * qq);
+                    const uint32_t bits = (v.x < 0.0f ? 1u : 0u) | (v.y < 0.0f ? 0x100u : 0u) | (v.z < 0.0f ? 0x10000u : 0u) |
+                                          (v.w < 0.0f ? 0x1000000u : 0u);
+                    *reinterpret_cast<uint32_t*>(hard + (size_t)c * ZC + 4 * qq) = bits;
+                }
+            });
+        } else {
+            const char* home = lds + cwbase + G::GUARD + 4 * z;
+            static_for<G::NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const float val = *reinterpret_cast<const float*>(home + c * G::CS);
+                if (c < G::KB) hard[(size_t)c * ZC + z] = val < 0.0f ? 1 : 0;
+                if (app_row) app_row[(size_t)c * ZC] = val * a.inv_scale;
+            });
+        }
     }
 }
 

@@ -189,3 +189,28 @@ def test_device_pointer_entry_and_timing(pkg, orc):
     assert (d_hard.cpu().numpy() == ho).all() and (d_it.cpu().numpy() == io).all()
     assert 0.0 < ms < 1000.0
     c.close()
+
+
+@pytest.mark.parametrize("bg,Z,dt", [(1, 384, np.float16), (2, 256, np.float32), (1, 320, np.float16)])
+def test_unaligned_device_pointers(pkg, orc, bg, Z, dt):
+    """The compile-time-Z kernels move LLRs and hard bits in 8/16-byte and 4-byte pieces when the caller's
+    pointers allow it; pointers at odd element offsets must take the narrow path and give the same answer."""
+    import torch
+    rng = np.random.default_rng(Z)
+    kb, B = BG_DIMS[bg][2], 9
+    info = rng.integers(0, 2, (B, kb * Z), dtype=np.uint8)
+    llr = awgn_llr(rng, orc.encode(bg, Z, info), 0.5, dt, Z)
+    tdt = torch.float16 if dt == np.float16 else torch.float32
+    for early in (True, False):
+        c = pkg.Codec(bg, Z, max_iter=6, early_term=early, llr_dtype=dt)
+        ref, ref_it = c.decode(llr, want_iters=True)
+        buf = torch.zeros(llr.size + 8, dtype=tdt, device="cuda")
+        buf[1:1 + llr.size] = torch.from_numpy(llr).cuda().flatten()          # one element off any 16-byte boundary
+        hard = torch.zeros(B * kb * Z + 8, dtype=torch.uint8, device="cuda")
+        it = torch.zeros(B, dtype=torch.int32, device="cuda")
+        c.decode_dev(buf.data_ptr() + buf.element_size(), B, hard.data_ptr() + 1, it.data_ptr(), None,
+                     torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        c.close()
+        assert (hard[1:1 + B * kb * Z].cpu().numpy().reshape(B, -1) == ref).all() and (it.cpu().numpy() == ref_it).all()
+        assert int(hard[0]) == 0 and int(hard[1 + B * kb * Z:].sum()) == 0
