@@ -77,6 +77,23 @@ def run(name, n_tb, harq, **props):
                                                       None, s)), n_tb * (C * K + B + 4))
     assert bool((ok != 0).all()) and bool((b_hat[:, :A] == a).all()), "chain round trip failed"
     codec.close()
+    # whole receive chain as NRLDPCDecoder.step runs it: g_tilde -> rate recovery -> decode (parity-check stop) -> CRC
+    DC = importlib.import_module("ldpc-3gpp-matlab_amd.device_chain")
+    esn0 = 13.0 if props["Q_m"] == 6 else (-0.5 if props["BG"] == 1 else (0.0 if Z > 64 else 2.5))
+    H = importlib.import_module("ldpc-3gpp-matlab_amd.harness")
+    N0 = 10 ** (-esn0 / 10)
+    tx = H.modulate_t(g, props["Q_m"])
+    rx = tx + (N0 / 2) ** 0.5 * torch.view_as_complex(torch.randn(tx.shape + (2,), device="cuda", dtype=torch.float64, generator=gen))
+    g_noisy = H.demodulate_llr_t(rx, props["Q_m"], N0).float().contiguous()
+    chain = DC.DeviceDecodeChain(p, iterations=25, llr_dtype=np.float16)
+    a_hat, okc, iters = chain.step(g_noisy)
+    ms = timed(lambda: chain.step(g_noisy), reps=5)
+    r = {"config": name, "stage": "receive chain (rate recovery + decode with parity-check stop + CRC)", "n_tb": n_tb, "C": C, "Z": Z,
+         "G": G, "ms": ms, "EsN0_dB": esn0, "tb_ok_fraction": float(okc.float().mean()), "mean_iters": float(iters.float().mean()),
+         "tb_per_s": n_tb / ms * 1e3, "payload_Gbit_s": n_tb * A / ms / 1e6}
+    print(r, flush=True)
+    out.append(r)
+    chain.close()
     return out
 
 
