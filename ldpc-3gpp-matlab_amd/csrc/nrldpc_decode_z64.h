@@ -1,4 +1,5 @@
-// nrldpc_decode_z64.h -- compile-time-Z specialisation of the layered NMS-Q decoder (Z a multiple of 64).
+// nrldpc_decode_z64.h -- compile-time-Z specialisation of the layered NMS-Q decoder.  Described for Z a multiple
+// of 64; for other Z every "64" below is the block size B = z64_blk(Z) < 64 and lanes B..63 of each wave retire.
 // Instantiated once per (BG, Z) by nrldpc_decode_z64_inst.hip (compiled with -DNRLDPC_Z64_BG / -DNRLDPC_Z64_Z).
 //
 // Same algorithm and results as nrldpc_decode.hip (the generic kernel is the reference for this one
@@ -35,29 +36,44 @@ constexpr int z64_set_index(int Z) {
     return -1;
 }
 
+// Rows per wave ("block"): 64 when 64 | Z, else the largest divisor of Z below 64 that is a multiple of 4.
+// A wave then owns B consecutive rows and its lanes B..63 retire at kernel entry (Z = 240 -> 4 waves of 60
+// rows, 94 % of the lanes busy; the run-time-Z kernel fills every lane but pays 12 VALU cycles per edge for
+// the ring address and runs at 0.55-0.7 of this kernel's rate).
+constexpr int z64_blk(int Z) {
+    if (Z % 64 == 0) return 64;
+    for (int b = 60; b >= 4; b -= 4)
+        if (Z % b == 0) return b;
+    return 0;
+}
+constexpr int z64_nwv(int Z) { return Z / z64_blk(Z); } // waves per codeword
+
 // Codewords per workgroup and waves per SIMD the register allocation is sized for (second
-// __launch_bounds__ argument in HIP), per (BG, Z): measured optima on MI355X (tools/exp_z64.sh builds one
-// variant, tools/bench_one.py times it).  What decides: waves resident per CU (BG1 needs ~128 VGPRs -> 4 waves
-// per SIMD = 16 per CU when the codeword's wave count divides into it, else 3; BG2 fits 80 VGPRs -> 6 per
-// SIMD), the 160 KB of LDS, an even spread of a workgroup's waves over the 4 SIMDs, and barrier width.
+// __launch_bounds__ argument in HIP), by waves per codeword: measured optima on MI355X (tools/exp_z64.sh
+// builds one variant, tools/bench_one.py times it).  What decides: waves resident per CU (BG1 needs ~128 VGPRs
+// -> 4 waves per SIMD = 16 per CU when the codeword's wave count divides into it, else 3; BG2 fits 80 VGPRs
+// -> 6 per SIMD), the 160 KB of LDS, an even spread of a workgroup's waves over the 4 SIMDs, barrier width.
 template <int BG, int ZC> constexpr int z64_ncwg() {
 #ifdef NRLDPC_Z64_NCWG
     return NRLDPC_Z64_NCWG;
 #endif
-    if (BG == 1) return ZC == 384 ? 2 : ZC == 320 ? 3 : ZC == 256 ? 2 : ZC == 192 ? 4 : 2;
-    return ZC == 384 ? 2 : ZC == 320 ? 1 : ZC == 256 ? 3 : ZC == 192 ? 4 : ZC == 128 ? 2 : 4;
+    constexpr int n = z64_nwv(ZC);
+    if (BG == 1) return n == 6 ? 2 : n == 5 ? 3 : n == 4 ? 2 : n == 3 ? 4 : 2;
+    return n == 6 ? 2 : n == 5 ? 1 : n == 4 ? 3 : n == 3 ? 4 : n == 2 ? 2 : 4;
 }
 
 template <int BG, int ZC, int NCWG> constexpr int z64_wpe() {
 #ifdef NRLDPC_Z64_WPE
     return NRLDPC_Z64_WPE;
 #endif
-    return BG == 2 ? 6 : (ZC == 320 || ZC == 256) ? 4 : 3;
+    return BG == 2 ? 6 : (z64_nwv(ZC) == 5 || z64_nwv(ZC) == 4) ? 4 : 3;
 }
 
 template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>()> struct Z64 : BGD<BG> {
-    static_assert(ZC % 64 == 0, "specialisation needs whole waves per codeword");
-    static constexpr int NWV = ZC / 64;                 // waves per codeword
+    static constexpr int BLK = z64_blk(ZC);             // rows (ring words) per wave
+    static_assert(BLK >= 4 && ZC % BLK == 0, "no usable block size for this lifting size");
+    static constexpr int NWV = ZC / BLK;                // waves per codeword
+    static constexpr int TPC = NWV * 64;                // threads per codeword (lanes BLK..63 of a wave retire)
     static constexpr int GUARD = 256;                   // bytes: 64 never-read words in front of every ring
     static constexpr int CS = GUARD + (ZC + 64) * 4;    // column stride in bytes (guard + ring + mirror)
     static constexpr int CWS = BGD<BG>::NC * CS;        // codeword stride in bytes
@@ -81,10 +97,10 @@ template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>()> struct Z64 : BGD<BG> {
     // output and the hard decision read the column through every edge / through the primary copy.
     static constexpr bool last_on_column(int e) { return next_on_column(e) <= e; }
     static constexpr bool twin_a(int e, bool full) {
-        return shift(e) % 64 != 0 && (!full || last_on_column(e) || shift(next_on_column(e)) % 64 < shift(e) % 64);
+        return shift(e) % BLK != 0 && (!full || last_on_column(e) || shift(next_on_column(e)) % BLK < shift(e) % BLK);
     }
     static constexpr bool twin_b(int e, bool full) {
-        return !full || last_on_column(e) || shift(next_on_column(e)) % 64 > shift(e) % 64;
+        return !full || last_on_column(e) || shift(next_on_column(e)) % BLK > shift(e) % BLK;
     }
     // + one trailing guard (the last column's block-0 twin write overshoots into it) + termination flags
     static constexpr size_t lds_bytes() { return (size_t)NCWG * CWS + GUARD + 16 * ((NCWG + 1 + 3) / 4); }
@@ -113,11 +129,11 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
     float t[ncore];
     float lam, m1, M1, M2;
 
-    __device__ __forceinline__ void load(const char* lds, const uint32_t (&R)[ZC / 64]) {
+    __device__ __forceinline__ void load(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int P = G::shift(e0 + j);
-            t[j] = *reinterpret_cast<const float*>(lds + R[P / 64] + G::col(e0 + j) * G::CS + 4 * (P % 64));
+            t[j] = *reinterpret_cast<const float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK));
         });
     }
 
@@ -132,12 +148,12 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
     float pm1, pm2;  // partial two-smallest search
     uint32_t pS;     // partial sign parity
 
-    template <bool LATE> __device__ __forceinline__ void load_part(const char* lds, const uint32_t (&R)[ZC / 64]) {
+    template <bool LATE> __device__ __forceinline__ void load_part(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (LayerZ64::is_late(j) == LATE) {
                 constexpr int P = G::shift(e0 + j);
-                t[j] = *reinterpret_cast<const float*>(lds + R[P / 64] + G::col(e0 + j) * G::CS + 4 * (P % 64));
+                t[j] = *reinterpret_cast<const float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK));
             }
         });
     }
@@ -178,7 +194,7 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
         }
     }
     // pass 2 for all edges after both parts have been tracked
-    __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
+    __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         m1 = pm1;
         // magnitudes carrying the row's sign parity: M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
         M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(rintf(a.alpha * pm1)), pS, 0x80000000u, 0xF8));
@@ -198,11 +214,11 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
             f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
             const float v = tj + r;
             t[j] = v;
-            *reinterpret_cast<float*>(lds + R[P / 64] + G::col(e0 + j) * G::CS + 4 * (P % 64)) = v;
+            *reinterpret_cast<float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK)) = v;
         });
     }
 
-    __device__ __forceinline__ void update(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
+    __device__ __forceinline__ void update(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         float mm1 = __builtin_inff(), mm2 = __builtin_inff();
         uint32_t S = 0, pend = 0;
         static_for<ncore>([&](auto jc) {
@@ -242,7 +258,7 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
             f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
             const float v = tj + r;
             t[j] = v; // kept for the mirror pass
-            *reinterpret_cast<float*>(lds + R[P / 64] + G::col(e0 + j) * G::CS + 4 * (P % 64)) = v;
+            *reinterpret_cast<float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK)) = v;
         });
     }
 
@@ -255,8 +271,8 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int P = G::shift(e0 + j);
-            constexpr int ka = P / 64;
-            constexpr int off = G::col(e0 + j) * G::CS + 4 * (P % 64);
+            constexpr int ka = P / G::BLK;
+            constexpr int off = G::col(e0 + j) * G::CS + 4 * (P % G::BLK);
             if constexpr ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
                           (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV)) {
                 if constexpr (G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV)
@@ -289,12 +305,12 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
 
 // Layers GS..GE (a column-disjoint barrier group, see LayerGroups) processed as one block of code.
 template <int BG, int ZC, int GS, int GE, bool FULL, bool PLAIN>
-__device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], uint32_t RA,
+__device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA,
                                           uint32_t RB, int w, const DecArgs& a, uint32_t& esign_lo,
                                           uint32_t& esign_hi, float* app_ext) {
     constexpr int N = GE - GS + 1;
     static_assert(N >= 1 && N <= 3, "group size");
-    constexpr int NWV = ZC / 64;
+    constexpr int NWV = z64_nwv(ZC);
     LayerZ64<BG, ZC, GS, FULL> l0;
     LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), FULL> l1;
     LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), FULL> l2;
@@ -329,7 +345,7 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
     std::conditional_t<(N > 1), LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true>, NoLayer> l1;
     std::conditional_t<(N > 2), LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true>, NoLayer> l2;
 
-    template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[ZC / 64]) {
+    template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
         l0.template load_part<LATE>(lds, R);
         if constexpr (N > 1) l1.template load_part<LATE>(lds, R);
         if constexpr (N > 2) l2.template load_part<LATE>(lds, R);
@@ -339,7 +355,7 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
         if constexpr (N > 1) l1.template track_part<LATE>(st, cap);
         if constexpr (N > 2) l2.template track_part<LATE>(st, cap);
     }
-    __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[ZC / 64], const DecArgs& a) {
+    __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         l0.finish(st, lds, R, a);
         if constexpr (N > 1) l1.finish(st, lds, R, a);
         if constexpr (N > 2) l2.finish(st, lds, R, a);
@@ -350,7 +366,7 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
         if constexpr (N > 2) l2.ext(a, esign_lo, esign_hi, nullptr);
     }
     __device__ __forceinline__ void twins(char* lds, uint32_t RA, uint32_t RB, int w) const {
-        dispatch_w<0, ZC / 64>(w, [&](auto wc) {
+        dispatch_w<0, z64_nwv(ZC)>(w, [&](auto wc) {
             constexpr int WV = decltype(wc)::value;
             l0.template twins<WV>(lds, RA, RB);
             if constexpr (N > 1) l1.template twins<WV>(lds, RA, RB);
@@ -366,7 +382,7 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
 // early-termination kernel needs it).
 template <int BG, int ZC, int GI, bool ET = false>
 __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI>& cur, GroupZ64<BG, ZC, 0>& next0, DecState<BG>& st,
-                                             char* lds, const uint32_t (&R)[ZC / 64], uint32_t RA, uint32_t RB,
+                                             char* lds, const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB,
                                              int w, const DecArgs& a, float cap, uint32_t& esign_lo,
                                              uint32_t& esign_hi) {
     constexpr int NG = LayerGroups<BG>::ngroups();
@@ -400,7 +416,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI>& cur, GroupZ64
 }
 
 template <int BG, int ZC, int L>
-__device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R)[ZC / 64], uint32_t esign_lo,
+__device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R)[z64_nwv(ZC)], uint32_t esign_lo,
                                                    uint32_t esign_hi) {
     using G = Z64<BG, ZC>;
     constexpr int e0 = G::row_ptr(L);
@@ -412,7 +428,7 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);
         constexpr int P = G::shift(e0 + j);
-        p ^= fbits(*reinterpret_cast<const float*>(lds + R[P / 64] + c * G::CS + 4 * (P % 64)));
+        p ^= fbits(*reinterpret_cast<const float*>(lds + R[P / G::BLK] + c * G::CS + 4 * (P % G::BLK)));
     });
     p >>= 31;
     if constexpr (HAS_EXT) p ^= (L - 4 < 32 ? esign_lo >> ((L - 4) & 31) : esign_hi >> ((L - 36) & 31)) & 1u;
@@ -425,7 +441,7 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
 // ETP  : FULL with early termination (no soft output): the pipelined iteration of PLAIN plus the sign of every
 //        extension-parity bit, then the parity pass; a finished codeword's waves only keep the barriers.
 template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false>
-__global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_decode_z64_kernel(const DecArgs a) {
+__global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_decode_z64_kernel(const DecArgs a) {
     static_assert(!PLAIN || FULL, "PLAIN implies FULL");
     static_assert(!ETP || (FULL && !PLAIN), "ETP implies FULL and excludes PLAIN");
     using G = Z64<BG, ZC, NCWG>;
@@ -433,7 +449,10 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cwl = wave / G::NWV, w = wave % G::NWV, lane = tid & 63;
-    const int z = w * 64 + lane;
+    if constexpr (G::BLK < 64) {
+        if (lane >= G::BLK) return; // these lanes own no row; barriers count waves, not lanes
+    }
+    const int z = w * G::BLK + lane;
     const int cw = blockIdx.x * G::NCWG + cwl;
     const bool active = cw < a.batch; // wave-uniform: whole waves belong to one codeword
     const uint32_t cwbase = (uint32_t)cwl * (uint32_t)G::CWS;
@@ -443,10 +462,10 @@ __global__ __launch_bounds__(NCWG * ZC, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_d
     uint32_t R[G::NWV];
 #pragma unroll
     for (int k = 0; k < G::NWV; ++k)
-        R[k] = cwbase + G::GUARD + 256u * (uint32_t)((w + k) % G::NWV) + 4u * (uint32_t)lane;
+        R[k] = cwbase + G::GUARD + (uint32_t)(4 * G::BLK) * (uint32_t)((w + k) % G::NWV) + 4u * (uint32_t)lane;
     // twin addresses: a run in the last block mirrors to ring word (kb+lane-64) => column base + 4(kb+lane);
     // a run in block 0 mirrors to ring word ZC+kb+lane
-    const uint32_t RA = cwbase + 4u * (uint32_t)lane;
+    const uint32_t RA = cwbase + (uint32_t)(G::GUARD - 4 * G::BLK) + 4u * (uint32_t)lane;
     const uint32_t RB = cwbase + G::GUARD + 4u * ZC + 4u * (uint32_t)lane;
 
     DecState<BG> st;
@@ -697,7 +716,7 @@ template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false> sta
         attr_set[dev & 63] = true;
     }
     const int grid = (a.batch + G::NCWG - 1) / G::NCWG;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(G::NCWG * ZC), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(G::NCWG * G::TPC), lds, s, a);
     return hipGetLastError();
 }
 

@@ -191,7 +191,7 @@ def test_device_pointer_entry_and_timing(pkg, orc):
     c.close()
 
 
-@pytest.mark.parametrize("bg,Z,dt", [(1, 384, np.float16), (2, 256, np.float32), (1, 320, np.float16)])
+@pytest.mark.parametrize("bg,Z,dt", [(1, 384, np.float16), (2, 256, np.float32), (1, 320, np.float16), (1, 240, np.float16), (2, 104, np.float32)])
 def test_unaligned_device_pointers(pkg, orc, bg, Z, dt):
     """The compile-time-Z kernels move LLRs and hard bits in 8/16-byte and 4-byte pieces when the caller's
     pointers allow it; pointers at odd element offsets must take the narrow path and give the same answer."""
