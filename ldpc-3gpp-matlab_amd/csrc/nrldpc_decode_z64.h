@@ -721,8 +721,8 @@ template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false> sta
 }
 
 template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
-    if (a.n_layers != BGD<BG>::ROWS) return launch_z64f<BG, ZC, NCWG, false, false>(a, s);
-    if (a.app) return launch_z64f<BG, ZC, NCWG, true, false>(a, s);
+    // pruned layer counts and soft output (a test / debug feature) share the unpipelined general kernel
+    if (a.n_layers != BGD<BG>::ROWS || a.app) return launch_z64f<BG, ZC, NCWG, false, false>(a, s);
     if (a.early_term) return launch_z64f<BG, ZC, NCWG, true, false, true>(a, s);
     return launch_z64f<BG, ZC, NCWG, true, true>(a, s);
 }
