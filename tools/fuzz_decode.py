@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Extended differential fuzz of the decoder kernels against the CPU oracle (the test-suite version runs 60
+cases; this runs N, default 600, biased towards the compile-time-Z sizes).  python tools/fuzz_decode.py [N] [seed]"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from conftest import ALL_Z, BG_DIMS
+import oracle as orc
+pkg = importlib.import_module("ldpc-3gpp-matlab_amd")
+T = importlib.import_module("test_decode_gpu")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+BIG = [z for z in ALL_Z if z >= 52]
+for i in range(N):
+    bg = int(rng.integers(1, 3))
+    Z = int(rng.choice(BIG)) if rng.random() < 0.75 else int(rng.choice(ALL_Z))
+    rows = BG_DIMS[bg][0]
+    nl = 0 if rng.random() < 0.5 else int(rng.integers(4, rows + 1))
+    T.run_case(pkg, orc, rng, bg, Z, int(rng.integers(1, 8)), float(rng.uniform(-2.0, 8.0)), int(rng.integers(1, 13)),
+               nl=nl, et=bool(rng.integers(0, 2)), dt=[np.float16, np.float32][int(rng.integers(0, 2))],
+               alpha=float(rng.choice([0.5, 0.625, 0.6875, 0.75, 0.8, 0.875, 1.0])),
+               scale=int(rng.choice([2, 4, 8, 16])), app=bool(rng.random() < 0.25))
+    if i % 50 == 49:
+        print("%d cases ok" % (i + 1), flush=True)
+print("fuzz ok:", N)
