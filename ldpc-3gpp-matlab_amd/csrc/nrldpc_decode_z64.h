@@ -645,14 +645,8 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
             using LG = LayerGroups<BG>;
             if constexpr (LG::group_start(L) == L) { // L leads a barrier group
                 constexpr int GE = LG::group_last(L);
-                if constexpr (FULL) { // every layer active: no per-layer predicates at all
-                    if constexpr (PLAIN) {
-                        if (active) group_z64<BG, ZC, L, GE, FULL, PLAIN>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
-                    } else {
-                        if (!done) group_z64<BG, ZC, L, GE, FULL, PLAIN>(st, lds, R, RA, RB, w, a, esign_lo, esign_hi, app_row);
-                    }
-                    __syncthreads();
-                } else {
+                static_assert(PLAIN || ETP || !FULL, "the unpipelined loop is built for run-time layer counts only");
+                {
                     const int nl = launder(a.n_layers);
                     if (L < nl) {
                         if (!done) {
