@@ -7,6 +7,16 @@
 #define NRLDPC_K_F32 0
 #define NRLDPC_K_F16 1
 
+#ifndef NRLDPC_GEN_THREADS_BG1
+#define NRLDPC_GEN_THREADS_BG1 512 // workgroup size cap of the run-time-Z kernel for BG1
+#endif
+#ifndef NRLDPC_GEN_THREADS_BG2
+#define NRLDPC_GEN_THREADS_BG2 512 // same for BG2 (register allocation: 6 waves per SIMD)
+#endif
+#ifndef NRLDPC_GEN_WPE_BG1
+#define NRLDPC_GEN_WPE_BG1 4     // waves per SIMD its register allocation is sized for
+#endif
+
 namespace nrldpc {
 
 struct DecArgs {

@@ -18,6 +18,8 @@
 
 #include "nr_bg_tables.h"
 
+#include "nrldpc_kernels.h"
+
 namespace nrldpc {
 
 struct BaseGraph {
@@ -86,13 +88,29 @@ inline bool build_schedule(int bg, int Z, int n_layers, Schedule* s) {
     s->n_layers = n_layers;
     s->nc = g.kb + 4;
     s->ncp = s->nc | 1;
-    // Codewords per workgroup: as many as fit 768 threads.  Consecutive ring positions of one codeword are
-    // ncw*ncp dwords apart in LDS and only an odd stride spreads a wave's lanes over all 32 banks: an even ncw
-    // means 2^k-way bank conflicts.  Measured (tools/bench_generic.py): up to 4-way is cheaper than a smaller
-    // workgroup (Z = 192, 320), beyond that an odd ncw wins by up to 3x (Z = 24: 32-way -> none).
-    int ncw = 768 / Z;
-    if (ncw < 1) ncw = 1;
-    if (ncw > 4 && (ncw & 1) == 0) --ncw;
+    // Codewords per workgroup.  The run-time-Z kernel's registers are sized for 4 waves per SIMD (BG1, 128
+    // VGPRs) / 6 (BG2, 80 VGPRs), i.e. 16 / 24 wave slots per CU; pick the ncw that keeps most of them doing
+    // useful work: lanes used per wave x wave slots the resulting workgroups can fill (also bounded by LDS).
+    // Consecutive ring positions of one codeword are ncw*ncp dwords apart in LDS and only an odd stride spreads
+    // a wave's lanes over all banks: an even ncw above 4 means 8-way or worse conflicts (Z = 24 ran 3x slower),
+    // so those are skipped.  Measured against the former "as many as fit 768 threads": +0..43 % (BG1).
+    const int slots = (bg == 1) ? 4 * NRLDPC_GEN_WPE_BG1 : 24, tmax = (bg == 1) ? NRLDPC_GEN_THREADS_BG1 : NRLDPC_GEN_THREADS_BG2;
+    int ncw = 1;
+    double best = -1.0;
+    for (int n = 1; n * Z <= tmax || n == 1; ++n) {
+        if (n > 4 && (n & 1) == 0) continue;
+        const int waves = (n * Z + 63) / 64;
+        const size_t lds = (size_t)Z * n * s->ncp * 4 + 4 * (size_t)(n + 1) + 16;
+        int wgs = slots / waves;
+        const int by_lds = (int)((160 * 1024) / lds);
+        if (wgs > by_lds) wgs = by_lds;
+        if (wgs < 1) wgs = 1;
+        double score = (double)(n * Z) / (waves * 64.0) * (double)(waves * wgs > slots ? slots : waves * wgs) / slots;
+        if (waves % 4) score *= (waves > 4 ? 0.85 : 0.97); // uneven spread over the 4 SIMDs (6-wave groups: -15 %)
+        if (waves < 4) score *= 0.97; // per-workgroup overheads weigh more on tiny workgroups
+        if (score >= best - 1e-9) { best = score; ncw = n; } // ties: the larger workgroup
+        if (n * Z > tmax) break;
+    }
     s->ncw = ncw;
     s->threads = ((ncw * Z + 63) / 64) * 64;
     s->sbw = ncw * s->ncp * 4;
