@@ -15,8 +15,10 @@ LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip.so")  # 
 OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_capi.hip"]
 Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
-Z64_SIZES = (52, 56, 60, 64, 88, 96, 104, 112, 120, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352, 384)
-Z64_PAIRS = [(bg, z) for bg in (1, 2) for z in Z64_SIZES if (bg, z) != (2, 56)]  # = NRLDPC_Z64_LIST (nrldpc_kernels.h)
+# = NRLDPC_Z64_LIST (nrldpc_kernels.h): the sizes where the compile-time-Z kernel beats the run-time-Z one
+Z64_BG1 = (60, 64, 104, 112, 120, 128, 144, 176, 192, 208, 224, 240, 256, 288, 320, 352, 384)
+Z64_BG2 = (52, 60, 64, 88, 96, 104, 112, 120, 128, 144, 192, 208, 224, 240, 256, 288, 320, 352, 384)
+Z64_PAIRS = [(1, z) for z in Z64_BG1] + [(2, z) for z in Z64_BG2]
 HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_wave.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

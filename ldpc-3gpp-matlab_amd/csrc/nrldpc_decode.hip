@@ -19,6 +19,8 @@
 //   * all values are integers carried in fp32 (exact below 2^24), so abs/neg modifiers, v_med3_f32
 //     and v_min_f32 do the min-sum in 8 VALU ops per edge for pass 1 and 7 for pass 2.
 // HBM sees each codeword once on the way in (ncols*Z LLRs) and K hard bits on the way out.
+#include <cstdlib>
+
 #include "nrldpc_device.h"
 
 namespace nrldpc {
@@ -313,7 +315,8 @@ template <int BG, int DT> static hipError_t launch_t(const DecArgs& a, int grid,
 }
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
-#define NRLDPC_Z64_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64_##b##_##z(a, stream);
+    static const bool force_generic = getenv("NRLDPC_FORCE_GENERIC") != nullptr; // A/B of the two kernels (tools/bench_all_z.py)
+#define NRLDPC_Z64_CASE(b, z) if (!force_generic && bg == b && a.Z == z) return launch_decode_z64_##b##_##z(a, stream);
     NRLDPC_Z64_LIST(NRLDPC_Z64_CASE)
 #undef NRLDPC_Z64_CASE
     const int grid = (a.batch + a.ncw - 1) / a.ncw;

@@ -38,8 +38,8 @@ hipError_t launch_decode_multi(int bg, int llr_kind, const DecArgs* d_tab, const
 // compile-time-Z specialisations (nrldpc_decode_z64_inst.hip), one per (BG, Z): every Z that splits into waves of
 // at least 40 rows where that beats the run-time-Z kernel (measured, tools/bench_all_z.py)
 #define NRLDPC_Z64_LIST(X) \
-    X(1, 52) X(1, 56) X(1, 60) X(1, 64) X(1, 88) X(1, 96) X(1, 104) X(1, 112) X(1, 120) X(1, 128) X(1, 144) X(1, 160) X(1, 176) X(1, 192) X(1, 208) X(1, 224) X(1, 240) X(1, 256) X(1, 288) X(1, 320) X(1, 352) X(1, 384) \
-    X(2, 52) X(2, 60) X(2, 64) X(2, 88) X(2, 96) X(2, 104) X(2, 112) X(2, 120) X(2, 128) X(2, 144) X(2, 160) X(2, 176) X(2, 192) X(2, 208) X(2, 224) X(2, 240) X(2, 256) X(2, 288) X(2, 320) X(2, 352) X(2, 384)
+    X(1, 60) X(1, 64) X(1, 104) X(1, 112) X(1, 120) X(1, 128) X(1, 144) X(1, 176) X(1, 192) X(1, 208) X(1, 224) X(1, 240) X(1, 256) X(1, 288) X(1, 320) X(1, 352) X(1, 384) \
+    X(2, 52) X(2, 60) X(2, 64) X(2, 88) X(2, 96) X(2, 104) X(2, 112) X(2, 120) X(2, 128) X(2, 144) X(2, 192) X(2, 208) X(2, 224) X(2, 240) X(2, 256) X(2, 288) X(2, 320) X(2, 352) X(2, 384)
 #define NRLDPC_Z64_DECL(bg, z) hipError_t launch_decode_z64_##bg##_##z(const DecArgs& a, hipStream_t stream);
 NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
 #undef NRLDPC_Z64_DECL
