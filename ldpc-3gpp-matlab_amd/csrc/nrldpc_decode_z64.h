@@ -58,7 +58,7 @@ template <int BG, int ZC> constexpr int z64_ncwg() {
     return NRLDPC_Z64_NCWG;
 #endif
     constexpr int n = z64_nwv(ZC);
-    if (BG == 1) return n == 8 ? 2 : n == 6 ? 2 : n == 5 ? 3 : n == 4 ? 2 : n == 3 ? 4 : 2;
+    if (BG == 1) return n == 8 ? 2 : n == 6 ? 2 : n == 5 ? 3 : n == 4 ? 2 : n == 3 ? 1 : 2;
     return n == 8 ? 1 : n == 6 ? 2 : n == 5 ? 1 : n == 4 ? 3 : n == 3 ? 4 : n == 2 ? 2 : 4;
 }
 
@@ -66,7 +66,7 @@ template <int BG, int ZC, int NCWG> constexpr int z64_wpe() {
 #ifdef NRLDPC_Z64_WPE
     return NRLDPC_Z64_WPE;
 #endif
-    return BG == 2 ? 6 : (z64_nwv(ZC) == 8 || z64_nwv(ZC) == 5 || z64_nwv(ZC) == 4) ? 4 : 3;
+    return BG == 2 ? 6 : (z64_nwv(ZC) == 8 || z64_nwv(ZC) == 5 || z64_nwv(ZC) == 4 || z64_nwv(ZC) == 3) ? 4 : 3;
 }
 
 template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>()> struct Z64 : BGD<BG> {
