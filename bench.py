@@ -181,7 +181,7 @@ def main():
                                  "%d B/codeword" % (N_CW * S_BYTES + K)},
             "bler": bler,
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # the CPU baseline is timed at N = 1 only
             n = min(args.cpu_sample, batch)
             out["cpu_baseline"] = cpu_baseline(llr[:n].double().cpu().numpy(), info[:n].cpu().numpy())
         print(json.dumps(out), flush=True)
