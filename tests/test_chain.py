@@ -1,5 +1,7 @@
 """Host-side TS 38.212 stages around the core (no GPU): CRC known answers and the rate-matching
 index maps checked against literal restatements of the reference's per-element loops."""
+import os
+
 import numpy as np
 import pytest
 
@@ -94,3 +96,32 @@ def test_modulation_maps_and_exact_llr(pkg):
     rx = H.modulate(np.zeros((1, 200000), np.uint8), 2) + np.sqrt(N0 / 2) * (rng.standard_normal((1, 100000)) + 1j * rng.standard_normal((1, 100000)))
     l = H.demodulate_llr(rx, 2, N0)
     assert abs(l.mean() - 2 / N0) < 0.05 and abs(l.var() - 4 / N0) < 0.2
+
+
+def _chain_golden():
+    import json
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "chain_golden.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    return g, [(n, json.loads(bytes(g[n + "/kw"]).decode())) for n in names]
+
+
+def test_chain_golden_fixture(pkg, orc):
+    """Committed vectors of the stages either side of the core (tests/golden/make_chain_golden.py): the CPU
+    restatements must still reproduce them -- CRC attachment + segmentation, oracle encoder, rate matching (host
+    mirror), rate recovery (literal loops of oracle/nrldpc_chain_oracle.c)."""
+    g, cases = _chain_golden()
+    assert len(cases) >= 4
+    for name, kw in cases:
+        p = pkg.NRLDPCEncoder(**kw)
+        p.validate()
+        a = g[name + "/a"]
+        n_tb = a.shape[0]
+        c = p.code_block_segmentation(p.crc_calculation(a)).reshape(n_tb * p.C, p.K)
+        assert (np.packbits(c, axis=1) == g[name + "/c_packed"]).all()
+        cw = orc.encode(p.BG, p.Z_c, c)
+        assert (np.packbits(cw, axis=1) == g[name + "/cw_packed"]).all()
+        gg = p.rate_match(cw.reshape(n_tb, p.C, -1)[:, :, 2 * p.Z_c:])
+        assert (np.packbits(gg, axis=1) == g[name + "/g_packed"]).all()
+        rr = orc.rate_recover(p.Z_c, p.C, p.K, int(p.K_prime), p.N, p.N_cb, p.k_0, p.Q_m, p.G, p.E_r, g[name + "/g_tilde"], None)
+        ref = g[name + "/rate_recovered"]
+        assert (np.isinf(rr) == np.isinf(ref)).all() and (rr[~np.isinf(ref)] == ref[~np.isinf(ref)]).all()
