@@ -247,7 +247,7 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
 }
 
 template <int BG, int DT>
-__global__ __launch_bounds__(768, BG == 2 ? 6 : NRLDPC_GEN_WPE_BG1) void nrldpc_decode_kernel(const DecArgs a, const int32_t* __restrict__ rot_tab) {
+__global__ __launch_bounds__(768, BG == 2 ? NRLDPC_GEN_WPE_BG2 : NRLDPC_GEN_WPE_BG1) void nrldpc_decode_kernel(const DecArgs a, const int32_t* __restrict__ rot_tab) {
     decode_body<BG, DT>(a, rot_tab, blockIdx.x);
 }
 
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(768, BG == 2 ? 6 : NRLDPC_GEN_WPE_BG1) void nrldpc_
 // is a one-workgroup kernel that leaves 255 CUs idle for >100 us; a hundred of them queue behind each other
 // (BASELINE configuration 4: 3.6 ms as 102 launches on 8 streams).
 template <int BG, int DT>
-__global__ __launch_bounds__(768, BG == 2 ? 6 : NRLDPC_GEN_WPE_BG1) void nrldpc_decode_multi_kernel(const DecArgs* __restrict__ tab,
+__global__ __launch_bounds__(768, BG == 2 ? NRLDPC_GEN_WPE_BG2 : NRLDPC_GEN_WPE_BG1) void nrldpc_decode_multi_kernel(const DecArgs* __restrict__ tab,
                                                                                   const int32_t* __restrict__ wg_start, int nb) {
     const ctab_t st = as_ctab(wg_start);
     int lo = 0, hi = nb; // wg_start[lo] <= blockIdx.x < wg_start[hi], wg_start[nb] = grid size

@@ -13,6 +13,9 @@
 #ifndef NRLDPC_GEN_THREADS_BG2
 #define NRLDPC_GEN_THREADS_BG2 512 // same for BG2 (register allocation: 6 waves per SIMD)
 #endif
+#ifndef NRLDPC_GEN_WPE_BG2
+#define NRLDPC_GEN_WPE_BG2 6
+#endif
 #ifndef NRLDPC_GEN_WPE_BG1
 #define NRLDPC_GEN_WPE_BG1 4     // waves per SIMD its register allocation is sized for
 #endif

@@ -94,7 +94,7 @@ inline bool build_schedule(int bg, int Z, int n_layers, Schedule* s) {
     // Consecutive ring positions of one codeword are ncw*ncp dwords apart in LDS and only an odd stride spreads
     // a wave's lanes over all banks: an even ncw above 4 means 8-way or worse conflicts (Z = 24 ran 3x slower),
     // so those are skipped.  Measured against the former "as many as fit 768 threads": +0..43 % (BG1).
-    const int slots = (bg == 1) ? 4 * NRLDPC_GEN_WPE_BG1 : 24, tmax = (bg == 1) ? NRLDPC_GEN_THREADS_BG1 : NRLDPC_GEN_THREADS_BG2;
+    const int slots = 4 * ((bg == 1) ? NRLDPC_GEN_WPE_BG1 : NRLDPC_GEN_WPE_BG2), tmax = (bg == 1) ? NRLDPC_GEN_THREADS_BG1 : NRLDPC_GEN_THREADS_BG2;
     int ncw = 1;
     double best = -1.0;
     for (int n = 1; n * Z <= tmax || n == 1; ++n) {
