@@ -10,11 +10,17 @@ codewords per GPU, LLRs already resident in HBM (fp16).  Codeword batches shard 
 data-path collective (weak scaling: 4096 codewords per GPU); torch.distributed is used only for the
 barrier and the max-over-ranks timing.  Rank 0 prints ONE JSON line.
 
-roofline.achieved uses the ALGORITHMIC bytes of SURVEY.md section 8(d) (a streaming layered decoder
-with s = 2 byte messages: 24 322 080 B per codeword) divided by the decode kernel's average duration
-measured with HIP events on the launch stream inside the library.  Because this decoder keeps a
-codeword on-chip for all 25 iterations, that figure may exceed the 8 TB/s HBM peak; `traffic` is the
-HBM byte count per launch measured with rocprofv3 PMC counters (profiles/), null if not collected.
+Timing: ONE loop.  The K timed launches are bracketed by barrier + synchronize (wall clock -> value,
+ms_per_step) and each launch is additionally bracketed by a HIP event pair recorded on the launch
+stream (-> roofline.kernel_ms = mean of the K event durations of the same K launches).
+
+roofline (primary, bound "hbm", as the north star prescribes): ALGORITHMIC bytes of SURVEY.md 8(d),
+a streaming layered decoder, at the storage width this kernel really uses (s = 1 byte per message:
+int8) = 12 161 568 B per codeword, divided by kernel_ms.  The decoder keeps a codeword in LDS/VGPRs
+for all 25 iterations, so this exceeds the HBM peak; `traffic` (rocprofv3 PMC, profiles/) is the
+real HBM byte count per launch and shows HBM is not what binds.  roofline.secondary is the bound that
+does: VALU issue (wave64 VALU instructions per launch from the committed PMC summary against
+1024 SIMDs x 2.4 GHz / 2 cycles), with the wave-cycle split (issuing / issue-stalled / parked).
 """
 import argparse
 import importlib
@@ -34,12 +40,28 @@ K = KB * Z                     # 8448 information bits per codeword
 N_CW = NCOLS * Z               # 26112 LLRs per codeword
 E_TX = 25344                   # transmitted bits at R = 1/3 (rv0, no repetition): all 66*Z of N
 ESN0_DB = -0.5                 # QPSK/AWGN operating point (plot_BLER_vs_SNR.m:105-106)
-S_BYTES = 2                    # storage bytes per LLR/message in the algorithmic-bytes model
-ALG_BYTES_PER_CW = ITERS * 4 * S_BYTES * NNZ * Z + N_CW * S_BYTES + K // 8  # 24 322 080
+S_BYTES = 1                    # storage bytes per message in the algorithmic-bytes model = the kernel's int8
+ALG_BYTES_PER_CW = ITERS * 4 * S_BYTES * NNZ * Z + N_CW * S_BYTES + K // 8  # 12 161 568
 HBM_PEAK_GBS = 8000.0
-# measured by tools/collect_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 corrections
-# of MI355X_MICROARCH.md applied); bytes per decode launch of BATCH codewords, or None.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2  # 256 CUs x 4 SIMDs, one wave64 VALU op per 2 cycles (MI355X_MICROARCH.md)
+# rocprofv3 summaries of this very command (tools/profile_gpu.sh + tools/summarise_profile.py); newest round first
+PROFILE_TAGS = ("r02", "r01")
+
+
+def _profile():
+    """(tag, pmc summary dict, traffic dict) of the newest committed profile of this bench, or (None, {}, {})."""
+    for tag in PROFILE_TAGS:
+        p = os.path.join(ROOT, "profiles", tag + "_bench_pmc_summary.json")
+        if os.path.exists(p):
+            try:
+                pmc = json.load(open(p))
+                tf = os.path.join(ROOT, "profiles", tag + "_traffic_bytes_per_launch.json")
+                if not os.path.exists(tf):
+                    tf = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
+                return tag, pmc, (json.load(open(tf)) if os.path.exists(tf) else {})
+            except Exception:
+                pass
+    return None, {}, {}
 
 
 def synth_llr(torch, codec, batch, seed, dev):
@@ -58,31 +80,63 @@ def synth_llr(torch, codec, batch, seed, dev):
     return info, llr.to(torch.float16).contiguous()
 
 
-def cpu_baseline(llr_host_f64, info_host):
+def cpu_baseline(llr_host_f64, info_host, rule):
     """Reference-semantics CPU path (flooding sum-product, double, parity-check early stop, the
-    comm.LDPCDecoder configuration of NRLDPCDecoder.m:120) restated in oracle/, single thread like
-    MATLAB's one-codeword step().  Bounded sample so the default run stays within minutes."""
+    comm.LDPCDecoder configuration of NRLDPCDecoder.m:120) restated in oracle/.  `value` is the single-thread
+    figure (MATLAB's one-codeword step()); BASELINE.md section 2's other rows ride along: the same decoder on
+    all host cores (cpu_ref_bp_mt) and the build's own algorithm on all cores (cpu_nms_mt).  Bounded samples."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
+    cores = os.cpu_count() or 1
+    n1 = min(llr_host_f64.shape[0], 256)
     O.lib().orc_set_threads(1)
+    t0 = time.perf_counter()
+    hard, iters = O.decode_bp_flood(BG, Z, llr_host_f64[:n1], ITERS, nthreads=1)
+    dt = time.perf_counter() - t0
+    ok = int((hard == info_host[:n1]).all(axis=1).sum())
     n = llr_host_f64.shape[0]
     t0 = time.perf_counter()
-    hard, iters = O.decode_bp_flood(BG, Z, llr_host_f64, ITERS, nthreads=1)
-    dt = time.perf_counter() - t0
-    ok = int((hard == info_host).all(axis=1).sum())
-    cores = os.cpu_count() or 1
+    hard_mt, iters_mt = O.decode_bp_flood(BG, Z, llr_host_f64, ITERS, nthreads=cores)
+    dt_mt = time.perf_counter() - t0
+    assert (hard_mt[:n1] == hard).all()
     O.lib().orc_set_threads(cores)
     t1 = time.perf_counter()
-    O.decode_nmsq(BG, Z, llr_host_f64, ITERS, early_term=False)
+    O.decode_nmsq(BG, Z, llr_host_f64, ITERS, early_term=False, alpha=rule[0], beta=rule[1] * 8)
     dt_nms = time.perf_counter() - t1
     return {
-        "value": n * K / dt / 1e9, "unit": "Gbit/s", "cores": 1, "kind": "port",
+        "value": n1 * K / dt / 1e9, "unit": "Gbit/s", "cores": 1, "kind": "port",
         "sample": "%d codewords of the same workload, flooding BP double, <=%d sweeps with parity-check stop "
-                  "(mean %.1f sweeps), %d/%d blocks correct, %.1f s" % (n, ITERS, float(iters.mean()), ok, n, dt),
+                  "(mean %.1f sweeps), %d/%d blocks correct, %.1f s" % (n1, ITERS, float(iters.mean()), ok, n1, dt),
         "host_cores_available": cores,
-        "nms_oracle_all_cores": {"value": n * K / dt_nms / 1e9, "unit": "Gbit/s", "cores": cores,
-                                 "sample": "%d codewords, layered NMS-Q oracle, 25 iterations, %.2f s" % (n, dt_nms)},
+        "cpu_ref_bp_mt": {"value": n * K / dt_mt / 1e9, "unit": "Gbit/s", "cores": cores,
+                          "sample": "%d codewords, same decoder, one codeword per thread, %.2f s" % (n, dt_mt)},
+        "cpu_nms_mt": {"value": n * K / dt_nms / 1e9, "unit": "Gbit/s", "cores": cores,
+                       "sample": "%d codewords, the build's layered offset min-sum (oracle), %d iterations, no early "
+                                 "stop, %.2f s" % (n, ITERS, dt_nms)},
     }
+
+
+def e2e_host_path(nrldpc, info_host, llr_host_f16, rule, reps=7):
+    """PCIe-inclusive rate through nrldpc_decode (host pointers, pageable arrays as a MEX gateway would hand them
+    over), same codewords, 25 iterations, no early stop; median of `reps` calls per boundary dtype.  Never `value`."""
+    out = {}
+    for name, dt in (("f16", np.float16), ("f64_matlab_double", np.float64)):
+        c = nrldpc.Codec(BG, Z, max_iter=ITERS, n_layers=0, early_term=False, llr_dtype=dt, alpha=rule[0], beta=rule[1])
+        x = llr_host_f16.astype(dt)
+        c.decode(x[:64])
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            h = c.decode(x)
+            ts.append(time.perf_counter() - t0)
+        c.close()
+        assert (h == info_host).all(axis=1).mean() > 0.99
+        ts.sort()
+        n = x.shape[0]
+        out[name] = {"ms_median": ts[len(ts) // 2] * 1e3, "ms_min": ts[0] * 1e3, "ms_max": ts[-1] * 1e3,
+                     "value": n * K / ts[len(ts) // 2] / 1e9, "unit": "Gbit/s", "runs": reps,
+                     "host_bytes_in": int(x.nbytes)}
+    return out
 
 
 def main():
@@ -91,7 +145,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="codewords per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=384, help="codewords for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="codewords for the all-core CPU baselines (0 = skip)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-path leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-time (nccl = RCCL)")
     args = ap.parse_args()
 
     import torch
@@ -106,18 +162,24 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     batch = args.batch
+    # alpha = 0: the C ABI's own check-node rule for this rate (nrldpc_default_rule), what a MEX gateway gets
     codec = nrldpc.Codec(BG, Z, max_iter=ITERS, n_layers=0, early_term=False, llr_dtype=np.float16,
                          device_id=local_rank)
+    rule = (codec.alpha, codec.beta)
     info, llr = synth_llr(torch, codec, batch, 0xC0DE + 1 + rank, dev)
     hard = torch.empty((batch, K), device=dev, dtype=torch.uint8)
-    stream = torch.cuda.current_stream().cuda_stream
+    tstream = torch.cuda.current_stream()
+    stream = tstream.cuda_stream
 
     def step():
         codec.decode_dev(llr.data_ptr(), batch, hard.data_ptr(), None, None, stream)
@@ -128,62 +190,85 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for e0, e1 in ev:  # events go onto the launch stream (torch's current stream is the one handed to the library)
+        e0.record(tstream)
         step()
+        e1.record(tstream)
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     bler = float((hard != info).any(dim=1).float().mean().item())
 
-    # per-launch kernel duration from HIP events recorded by the library on the launch stream
-    codec.set_timing(True)
-    kms = []
-    for _ in range(args.steps):
-        step()
-        kms.append(codec.last_kernel_ms())
-    codec.set_timing(False)
-    kernel_ms = float(np.mean(kms))
-
     if rank == 0:
         value = world * batch * args.steps * K / elapsed / 1e9
         achieved = batch * ALG_BYTES_PER_CW / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        if os.path.exists(TRAFFIC_FILE):
-            try:
-                traffic = json.load(open(TRAFFIC_FILE)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        tag, pmc, tr = _profile()
+        traffic = tr.get("hbm_bytes_per_launch")
+        scale = batch / float(BATCH)  # the committed profile is of the default batch
+
+        def c(name):
+            v = pmc.get(name, {}).get("mean_per_launch")
+            return None if v is None else v * scale
+        secondary = None
+        if c("SQ_INSTS_VALU"):
+            insts = c("SQ_INSTS_VALU")
+            rate = insts / (kernel_ms * 1e-3)
+            wc = c("SQ_WAVE_CYCLES")
+            secondary = {
+                "bound": "valu_issue", "insts_per_launch": insts, "achieved": rate, "peak": VALU_PEAK_WAVE_INSTS,
+                "unit": "wave64 VALU instructions/s", "frac": rate / VALU_PEAK_WAVE_INSTS,
+                "valu_insts_per_edge_iteration": insts / (batch * ITERS * NNZ * Z / 64.0),
+                "wave_cycle_split": None if not wc else {
+                    "issuing": c("SQ_ACTIVE_INST_ANY") / wc, "issue_stalled": c("SQ_WAIT_INST_ANY") / wc,
+                    "parked_at_waitcnt_or_barrier": c("SQ_WAIT_ANY") / wc},
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                "valu_pipe_busy": (4.0 * c("SQ_ACTIVE_INST_VALU") / (1024 * c("GRBM_GUI_ACTIVE") / 8.0))
+                if (c("SQ_ACTIVE_INST_VALU") and c("GRBM_GUI_ACTIVE")) else None,
+                "source": "profiles/%s_bench_pmc_summary.json (rocprofv3 --pmc, separate passes); peak = 1024 SIMDs x "
+                          "2.4 GHz / 2 cycles per wave64 VALU op; instruction counts are per launch and "
+                          "data-independent without early termination" % tag,
+            }
         out = {
             "metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
             "value": value, "unit": "Gbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i8 messages / integer-valued f32 a-posteriori (fp16 LLR input)",
             "data": "synthetic",
-            "config": {"workload": "BG1 Z=384 (K=8448) R=1/3, 25 layered NMS iterations, no early termination, "
+            "config": {"workload": "BG1 Z=384 (K=8448) R=1/3, 25 layered min-sum iterations, no early termination, "
                                    "batch=%d codewords per GPU, QPSK/AWGN Es/N0=%.1f dB" % (batch, ESN0_DB),
                        "bg": BG, "Z": Z, "iterations": ITERS, "batch_per_gpu": batch, "n_layers": 46,
+                       "check_node_rule": {"alpha": rule[0], "beta_llr": rule[1], "source": "nrldpc_default_rule (cfg.alpha = 0)"},
                        "sharding": "codeword batches per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "nrldpc::nrldpc_decode_z64_kernel<1, 384, 2, true, true, false>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_codeword": ALG_BYTES_PER_CW,
+                         "algorithmic_bytes_per_codeword": ALG_BYTES_PER_CW, "storage_bytes_per_message": S_BYTES,
                          "hbm_achieved_GBs_from_traffic": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-                         "note": "algorithmic = streaming-model bytes (SURVEY 8d, s=2); codewords stay in "
-                                 "LDS/VGPRs for all iterations so frac may exceed 1; compulsory HBM I/O is "
-                                 "%d B/codeword" % (N_CW * S_BYTES + K)},
+                         "hbm_frac_from_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "note": "algorithmic = streaming-model bytes (SURVEY 8d) at the kernel's own storage width "
+                                 "s=1; a codeword stays in LDS/VGPRs for all iterations, so frac exceeds 1 and real "
+                                 "HBM traffic is the compulsory %d B/codeword (traffic / batch): HBM does not bind, "
+                                 "VALU issue does (secondary)" % (N_CW * 2 + K),
+                         "secondary": secondary},
             "bler": bler,
         }
-        if args.cpu_sample > 0 and world == 1:  # the CPU baseline is timed at N = 1 only
-            n = min(args.cpu_sample, batch)
-            out["cpu_baseline"] = cpu_baseline(llr[:n].double().cpu().numpy(), info[:n].cpu().numpy())
+        if world == 1:  # CPU baseline and host-path legs at N = 1 only
+            if args.cpu_sample > 0:
+                n = min(args.cpu_sample, batch)
+                out["cpu_baseline"] = cpu_baseline(llr[:n].double().cpu().numpy(), info[:n].cpu().numpy(), rule)
+            if not args.no_e2e:
+                out["e2e"] = e2e_host_path(nrldpc, info.cpu().numpy(), llr.cpu().numpy(), rule)
+                out["e2e"]["note"] = "host pointers in and out (PCIe + host copies included); never `value`"
         print(json.dumps(out), flush=True)
     codec.close()
     if dist is not None:

@@ -55,11 +55,14 @@ typedef struct nrldpc_cfg {
     int32_t n_layers;   /* base rows to decode, 4..46 (BG1) / 4..42 (BG2); 0 = all (reference: all) */
     int32_t max_iter;   /* 'MaximumIterationCount' (NRLDPCDecoder.m:41,120); 1..2000              */
     int32_t early_term; /* 1 = stop a codeword when all active parity checks hold (reference: 1)  */
-    float alpha;        /* min-sum normalisation factor, 0 < alpha <= 1; 0 selects the default 0.75 */
+    float alpha;        /* min-sum normalisation factor, 0 < alpha <= 1; 0 = choose alpha AND beta by code rate
+                           (nrldpc_default_rule: the rule whose BLER sits closest to the reference's sum-product) */
     int32_t llr_scale;  /* fixed-point units per unit LLR: power of two 1..32; 0 = default 8 */
     int32_t llr_dtype;  /* NRLDPC_LLR_*                                                            */
     int32_t device_id;  /* HIP device ordinal                                                      */
     int32_t max_batch;  /* staging capacity of the host entry points; 0 = grow on demand          */
+    float beta;         /* min-sum offset in LLR units (>= 0), read only when alpha != 0: message magnitude =
+                           max(alpha*min - beta, 0) on the fixed-point grid; 0 = plain normalised min-sum       */
 } nrldpc_cfg;
 
 /* Dimensions implied by (bg, Z): ncols*Z LLRs in, K = kb*Z hard bits out. */
@@ -68,6 +71,7 @@ typedef struct nrldpc_dims {
     int32_t i_ls;             /* set index (get_3gpp_set_index.m) */
     int32_t K, N_cw;          /* kb*Z, ncols*Z */
     int32_t n_layers;         /* resolved active layer count */
+    float alpha, beta;        /* resolved check-node rule (beta in LLR units) */
 } nrldpc_dims;
 
 int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out);
@@ -138,6 +142,11 @@ int nrldpc_rate_match_dev(const nrldpc_tb_params* p, const uint8_t* d_cw, int32_
  * launch stream; nrldpc_last_kernel_ms synchronises on the stop event and returns the duration. */
 int nrldpc_set_timing(nrldpc_handle h, int32_t enabled);
 int nrldpc_last_kernel_ms(nrldpc_handle h, float* ms);
+
+/* Check-node rule nrldpc_create applies when cfg.alpha == 0, by base graph and active layer count (0 = all):
+ * the (alpha, beta) pair measured closest to flooding sum-product (the reference's comm.LDPCDecoder,
+ * NRLDPCDecoder.m:120) at equal iteration caps; DESIGN.md section 6 holds the measurements.  beta in LLR units. */
+int nrldpc_default_rule(int32_t bg, int32_t n_layers, float* alpha, float* beta);
 
 /* Parameter helpers shared with the host-side chain (no device work). */
 int nrldpc_set_index(int32_t Z);                        /* get_3gpp_set_index.m:5-11; -1 if invalid  */

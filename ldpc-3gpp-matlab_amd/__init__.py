@@ -7,9 +7,9 @@ The package directory name contains hyphens; import it with
 from . import _capi, chain
 from ._capi import (Codec, NRLDPCError, UnsupportedParameters, crc_attach_dev, crc_check_dev, lifting_size, load,
                     rate_match_dev, rate_recover_dev, set_index, tb_params, decode_multi_dev)
-from .decoder import NRLDPCDecoder, default_alpha
+from .decoder import NRLDPCDecoder, default_rule
 from .encoder import NRLDPCEncoder
 from .nrldpc import NRLDPC, get_3gpp_crc_polynomial
 
 __all__ = ["Codec", "NRLDPC", "NRLDPCDecoder", "NRLDPCEncoder", "NRLDPCError", "UnsupportedParameters",
-           "chain", "crc_attach_dev", "crc_check_dev", "decode_multi_dev", "rate_match_dev", "default_alpha", "rate_recover_dev", "tb_params", "get_3gpp_crc_polynomial", "lifting_size", "load", "set_index", "_capi"]
+           "chain", "crc_attach_dev", "crc_check_dev", "decode_multi_dev", "rate_match_dev", "default_rule", "rate_recover_dev", "tb_params", "get_3gpp_crc_polynomial", "lifting_size", "load", "set_index", "_capi"]

@@ -28,12 +28,12 @@ class NRLDPCError(RuntimeError):
 class Cfg(C.Structure):
     _fields_ = [("bg", C.c_int32), ("Z", C.c_int32), ("n_layers", C.c_int32), ("max_iter", C.c_int32),
                 ("early_term", C.c_int32), ("alpha", C.c_float), ("llr_scale", C.c_int32),
-                ("llr_dtype", C.c_int32), ("device_id", C.c_int32), ("max_batch", C.c_int32)]
+                ("llr_dtype", C.c_int32), ("device_id", C.c_int32), ("max_batch", C.c_int32), ("beta", C.c_float)]
 
 
 class Dims(C.Structure):
     _fields_ = [("nrows", C.c_int32), ("ncols", C.c_int32), ("kb", C.c_int32), ("i_ls", C.c_int32),
-                ("K", C.c_int32), ("N_cw", C.c_int32), ("n_layers", C.c_int32)]
+                ("K", C.c_int32), ("N_cw", C.c_int32), ("n_layers", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float)]
 
 
 MAX_C = 160
@@ -59,7 +59,7 @@ def tb_params(p):
 
 EXPORTS = ["nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
            "nrldpc_decode_multi_dev", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
-           "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_strerror", "nrldpc_last_error",
+           "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version"]
 
 _lib = None
@@ -107,6 +107,7 @@ def load():
     L.nrldpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nrldpc_set_index.argtypes = [i32]
     L.nrldpc_lifting_size.argtypes = [i32, i32]
+    L.nrldpc_default_rule.argtypes = [i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     for f in ("nrldpc_strerror", "nrldpc_last_error", "nrldpc_version"):
         getattr(L, f).restype = C.c_char_p
     L.nrldpc_strerror.argtypes = [i32]
@@ -140,19 +141,22 @@ class Codec:
     comm.LDPCDecoder / comm.LDPCEncoder in the reference (NRLDPCDecoder.m:120, NRLDPCEncoder.m:49)."""
 
     def __init__(self, bg, Z, max_iter=50, n_layers=0, early_term=True, alpha=0.0, llr_scale=0,
-                 llr_dtype=np.float32, device_id=0, max_batch=0):
+                 llr_dtype=np.float32, device_id=0, max_batch=0, beta=0.0):
+        """alpha = 0: the library picks the check-node rule (alpha, beta) by rate (nrldpc_default_rule);
+        otherwise message magnitude = max(alpha*min - beta, 0), beta in LLR units."""
         L = load()
         self._lib = L
         self._h = C.c_void_p()
         self.llr_dtype = np.dtype(llr_dtype)
         cfg = Cfg(int(bg), int(Z), int(n_layers), int(max_iter), int(bool(early_term)), float(alpha),
-                  int(llr_scale), _NP2DT[self.llr_dtype], int(device_id), int(max_batch))
+                  int(llr_scale), _NP2DT[self.llr_dtype], int(device_id), int(max_batch), float(beta))
         check(L.nrldpc_create(C.byref(cfg), C.byref(self._h)))
         d = Dims()
         check(L.nrldpc_get_dims(self._h, C.byref(d)))
         self.bg, self.Z = int(bg), int(Z)
         self.K, self.N_cw, self.kb, self.ncols, self.nrows = d.K, d.N_cw, d.kb, d.ncols, d.nrows
         self.i_ls, self.n_layers = d.i_ls, d.n_layers
+        self.alpha, self.beta = float(d.alpha), float(d.beta)  # resolved check-node rule
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -243,6 +247,13 @@ def crc_attach_dev(p, d_a, n_tb, d_c, stream=0):
 def rate_match_dev(p, d_cw, n_tb, d_g, stream=0):
     t = p if isinstance(p, TbParams) else tb_params(p)
     check(load().nrldpc_rate_match_dev(C.byref(t), _ptr(d_cw), int(n_tb), _ptr(d_g), C.c_void_p(stream)))
+
+
+def default_rule(bg, n_layers=0):
+    """(alpha, beta) nrldpc_create uses when cfg.alpha == 0 (beta in LLR units)."""
+    a, b = C.c_float(), C.c_float()
+    check(load().nrldpc_default_rule(int(bg), int(n_layers), C.byref(a), C.byref(b)))
+    return float(a.value), float(b.value)
 
 
 def set_index(Z):

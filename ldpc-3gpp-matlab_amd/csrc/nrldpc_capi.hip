@@ -137,7 +137,7 @@ public:
 struct nrldpc_codec {
     nrldpc_cfg cfg;
     nrldpc::Schedule sched;
-    float alpha = 0.75f;
+    float alpha = 0.75f, beta = 0.0f; // beta in LLR units; the kernels get beta*scale
     int scale = 8;
     // device tables
     DevBuf<int32_t> d_rot;
@@ -233,6 +233,7 @@ nrldpc::DecArgs make_dec_args(const nrldpc_codec* h, const void* d_llr, int batc
     a.need_ext = (a.early_term || d_app) ? 1 : 0;
     a.llr_kind = (h->cfg.llr_dtype == NRLDPC_LLR_F16) ? NRLDPC_K_F16 : NRLDPC_K_F32;
     a.alpha = h->alpha; a.scale = (float)h->scale; a.inv_scale = 1.0f / (float)h->scale;
+    a.beta = h->beta * (float)h->scale;
     return a;
 }
 
@@ -286,6 +287,18 @@ const char* nrldpc_strerror(int code) {
 const char* nrldpc_last_error(void) { return g_err.c_str(); }
 const char* nrldpc_version(void) { return "nrldpc-hip 0.1 (gfx950)"; }
 
+int nrldpc_default_rule(int32_t bg, int32_t n_layers, float* alpha, float* beta) {
+    if (bg != 1 && bg != 2) return fail(NRLDPC_ERR_UNSUPPORTED, "BG must be 1 or 2");
+    const int rows = bg == 1 ? NR_BG1_ROWS : NR_BG2_ROWS;
+    if (n_layers == 0) n_layers = rows;
+    if (n_layers < 4 || n_layers > rows) return fail(NRLDPC_ERR_UNSUPPORTED, "n_layers must be 0 or in 4..rows of the base graph");
+    float a, b;
+    nrldpc::default_rule(bg, n_layers, &a, &b);
+    if (alpha) *alpha = a;
+    if (beta) *beta = b;
+    return NRLDPC_OK;
+}
+
 int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
     if (!cfg || !out) return fail(NRLDPC_ERR_ARG, "null cfg/out");
     *out = nullptr;
@@ -294,8 +307,15 @@ int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
     if (cfg->max_iter < 1 || cfg->max_iter > 2000) return fail(NRLDPC_ERR_UNSUPPORTED, "max_iter must be in 1..2000");
     if (cfg->llr_dtype < NRLDPC_LLR_F32 || cfg->llr_dtype > NRLDPC_LLR_F64)
         return fail(NRLDPC_ERR_UNSUPPORTED, "unknown llr_dtype");
-    float alpha = cfg->alpha == 0.0f ? 0.75f : cfg->alpha;
+    float alpha = cfg->alpha, beta = cfg->beta;
+    if (alpha == 0.0f) { // the caller leaves the check-node rule to the library: by rate (see nrldpc_default_rule)
+        const int rows = cfg->bg == 1 ? NR_BG1_ROWS : NR_BG2_ROWS;
+        if (cfg->n_layers != 0 && (cfg->n_layers < 4 || cfg->n_layers > rows))
+            return fail(NRLDPC_ERR_UNSUPPORTED, "n_layers must be 0 or in 4..rows of the base graph");
+        nrldpc::default_rule(cfg->bg, cfg->n_layers ? cfg->n_layers : rows, &alpha, &beta);
+    }
     if (!(alpha > 0.0f && alpha <= 1.0f)) return fail(NRLDPC_ERR_UNSUPPORTED, "alpha must be in (0,1]");
+    if (!(beta >= 0.0f && beta <= 4.0f)) return fail(NRLDPC_ERR_UNSUPPORTED, "beta must be in [0,4] LLR units");
     int scale = cfg->llr_scale == 0 ? 8 : cfg->llr_scale;
     if (scale != 1 && scale != 2 && scale != 4 && scale != 8 && scale != 16 && scale != 32)
         return fail(NRLDPC_ERR_UNSUPPORTED, "llr_scale must be a power of two in 1..32");
@@ -303,6 +323,7 @@ int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
     if (!h) return fail(NRLDPC_ERR_NOMEM, "host allocation failed");
     h->cfg = *cfg;
     h->alpha = alpha;
+    h->beta = beta;
     h->scale = scale;
     if (!nrldpc::build_schedule(cfg->bg, cfg->Z, cfg->n_layers, &h->sched)) {
         delete h;
@@ -368,6 +389,7 @@ int nrldpc_get_dims(nrldpc_handle h, nrldpc_dims* out) {
     const nrldpc::Schedule& s = h->sched;
     out->nrows = s.g.nrows; out->ncols = s.g.ncols; out->kb = s.g.kb; out->i_ls = s.ils;
     out->K = s.g.kb * s.Z; out->N_cw = s.g.ncols * s.Z; out->n_layers = s.n_layers;
+    out->alpha = h->alpha; out->beta = h->beta;
     return NRLDPC_OK;
 }
 

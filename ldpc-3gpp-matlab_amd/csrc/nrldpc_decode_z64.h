@@ -165,7 +165,7 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
         return n;
     }
     template <bool LATE> __device__ __forceinline__ void track_part(const DecState<BG>& st, float cap) {
-        // cap = 127.49/alpha: the search starts from it, so alpha*m never exceeds 127 and needs no clamp
+        // cap = (127.49 + beta)/alpha: the search starts from it, so alpha*m - beta never rounds above 127 and needs no upper clamp
         if constexpr (!LATE) { pm1 = cap; pm2 = cap; pS = 0; }
         uint32_t pend = 0;
         static_for<ncore>([&](auto jc) {
@@ -197,8 +197,8 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
     __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         m1 = pm1;
         // magnitudes carrying the row's sign parity: M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
-        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(rintf(a.alpha * pm1)), pS, 0x80000000u, 0xF8));
-        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(rintf(a.alpha * pm2)), pS, 0x80000000u, 0xF8));
+        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag<true>(a, pm1)), pS, 0x80000000u, 0xF8));
+        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag<true>(a, pm2)), pS, 0x80000000u, 0xF8));
         bool ismin[ncore]; // all compares first: keeps v_cmp -> v_cndmask hazard slots filled with useful work
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -246,8 +246,8 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
         m1 = mm1;
         // magnitudes carrying the row's sign parity (M | (S & signbit), one v_bitop3_b32); the edge's own sign is
         // xor-ed in per edge
-        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(fminf(rintf(a.alpha * mm1), 127.0f)), S, 0x80000000u, 0xF8));
-        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(fminf(rintf(a.alpha * mm2), 127.0f)), S, 0x80000000u, 0xF8));
+        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag<false>(a, mm1)), S, 0x80000000u, 0xF8));
+        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag<false>(a, mm2)), S, 0x80000000u, 0xF8));
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int ce = ce0 + j;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
     if constexpr (PLAIN) {
         // fixed-iteration path: barrier groups software-pipelined (see pipeline_z64)
         if (active) {
-            const float cap = 127.49f / a.alpha; // see track_part
+            const float cap = (127.49f + a.beta) / a.alpha; // see track_part
             GroupZ64<BG, ZC, 0> g0;
             g0.template loads<false>(lds, R);
             g0.template track<false>(st, cap);
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
         // Two loops, so that everything live in the decoding loop is unconditional (as in PLAIN): a wave
         // whose codeword has converged (or does not exist) drops into the second loop and only keeps the
         // barrier count of its workgroup until every codeword of it is done.
-        const float cap = 127.49f / a.alpha;
+        const float cap = (127.49f + a.beta) / a.alpha;
         int it = 1;
         bool all_done = false;
         if (active) {

@@ -151,6 +151,15 @@ __device__ __forceinline__ float ingest(float x, float scale, bool core) {
     return y;
 }
 
+// Row minimum m -> message magnitude clamp(rint(alpha*m - beta), 0, 127): one fused multiply-add, then round to
+// nearest even, exactly as scale_mag() of the oracle.  CAPPED: the caller's search started from
+// (127.49 + beta)/alpha, so the upper clamp cannot bind and is left out.
+template <bool CAPPED> __device__ __forceinline__ float scale_mag(const DecArgs& a, float m) {
+    const float x = rintf(__builtin_fmaf(a.alpha, m, -a.beta));
+    if constexpr (CAPPED) return fmaxf(x, 0.0f);
+    else return __builtin_amdgcn_fmed3f(x, 0.0f, 127.0f);
+}
+
 template <int BG> struct DecState {
     uint32_t rm[BGD<BG>::NW];  // check-to-variable messages, int8 x4
     uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4

@@ -31,6 +31,7 @@ struct DecArgs {
     int32_t batch, Z, n_layers, max_iter, ncw, sbw;
     int32_t early_term, need_ext, llr_kind;
     float alpha, scale, inv_scale;
+    float beta;          // offset in grid units: message magnitude = clamp(rint(alpha*m - beta), 0, 127)
 };
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream);

@@ -62,6 +62,22 @@ inline int lifting_size(int K_b, int K_prime) {
     return best;
 }
 
+// Check-node rule used when the caller does not give one (nrldpc_cfg.alpha == 0): message magnitude =
+// max(alpha*min - beta, 0), beta in LLR units.  The reference defines no such parameters (its decoder is
+// sum-product, NRLDPCDecoder.m:120); these are the values whose block-error rate sits closest to flooding
+// sum-product at equal iteration caps, measured per base graph and fraction of rows decoded
+// (tools/alg_search).
+inline void default_rule(int bg, int n_layers, float* alpha, float* beta) {
+    const int rows = bg == 1 ? NR_BG1_ROWS : NR_BG2_ROWS;
+    const double frac = (double)n_layers / rows;
+    // alpha = 7/8 everywhere; the offset grows with the share of degree-1 extension rows in the decoded graph.
+    // BG1 Z=384 R=1/3, 25 iterations, BLER 1e-2: plain alpha = 0.625 (round 1) sits 0.20 dB from flooding sum-product
+    // at the same cap, this rule 0.03 dB; at high rates (few extension rows) it beats sum-product at equal caps.
+    *alpha = 0.875f;
+    if (bg == 1) *beta = frac > 0.2 ? 0.375f : 0.25f;
+    else *beta = frac > 0.25 ? 0.3125f : 0.25f;
+}
+
 struct Schedule {
     BaseGraph g;
     int Z = 0, ils = 0, n_layers = 0;

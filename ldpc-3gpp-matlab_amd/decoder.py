@@ -20,27 +20,23 @@ from ._capi import Codec, NRLDPCError
 from .nrldpc import NRLDPC
 
 
-def default_alpha(bg, n_layers):
-    """Min-sum normalisation by code rate (the reference defines none; tuned on BLER vs its
-    sum-product semantics): low-rate graphs with many degree-1 extension rows want a
-    smaller factor."""
-    frac = n_layers / (46.0 if bg == 1 else 42.0)
-    if frac > 0.6:
-        return 0.625
-    if frac > 0.3:
-        return 0.6875
-    return 0.75
+def default_rule(bg, n_layers=0):
+    """(alpha, beta) of the check-node rule the library applies when none is given: it lives in the C ABI
+    (nrldpc_default_rule / nrldpc_create with cfg.alpha == 0), so that a MEX gateway gets the same decoder."""
+    from ._capi import default_rule as _dr
+    return _dr(bg, n_layers)
 
 
 class NRLDPCDecoder(NRLDPC):
     _NONTUNABLE = NRLDPC._NONTUNABLE + ("I_HARQ",)
     _TUNABLE = NRLDPC._TUNABLE + ("iterations",)
 
-    def __init__(self, device_id=0, alpha=None, llr_scale=0, prune_layers=True, **kw):
+    def __init__(self, device_id=0, alpha=None, llr_scale=0, prune_layers=True, beta=0.0, **kw):
         self._I_HARQ = 0        # NRLDPCDecoder.m:34
         self._iterations = 50   # NRLDPCDecoder.m:41
         super().__init__(**kw)
         self._device_id, self._alpha, self._llr_scale = device_id, alpha, llr_scale
+        self._beta = beta  # read only with an explicit alpha (nrldpc_cfg.beta)
         self._prune = prune_layers
         self._codec = None
         self._codec_layers = None
@@ -68,9 +64,8 @@ class NRLDPCDecoder(NRLDPC):
     def _make_codec(self, n_layers):
         if self._codec is not None:
             self._codec.close()
-        alpha = self._alpha if self._alpha is not None else default_alpha(self.BG, n_layers)
         self._codec = Codec(self.BG, self.Z_c, max_iter=self._setup_iterations, n_layers=n_layers,
-                            early_term=True, alpha=alpha, llr_scale=self._llr_scale,
+                            early_term=True, alpha=self._alpha or 0.0, beta=self._beta, llr_scale=self._llr_scale,
                             llr_dtype=np.float32, device_id=self._device_id)
         self._codec_layers = n_layers
 

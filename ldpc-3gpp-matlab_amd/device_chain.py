@@ -7,7 +7,6 @@ with no host loop and no PCIe traffic in between.  torch is used for device memo
 import numpy as np
 
 from ._capi import LLR_F16, LLR_F32, Codec, NRLDPCError, crc_check_dev, rate_recover_dev, tb_params
-from .decoder import default_alpha
 from .nrldpc import NRLDPC
 
 
@@ -16,13 +15,13 @@ class DeviceDecodeChain:
     NRLDPCDecoder); HARQ soft buffers live in HBM when I_HARQ is set."""
 
     def __init__(self, params: NRLDPC, iterations=50, I_HARQ=0, alpha=None, llr_scale=0, prune_layers=True,
-                 llr_dtype=np.float16, device_id=0):
+                 llr_dtype=np.float16, device_id=0, beta=0.0):
         import torch
         self.torch = torch
         params.validate()
         self.p = params
         self.iterations, self.I_HARQ = int(iterations), int(I_HARQ)
-        self.alpha, self.llr_scale, self.prune = alpha, llr_scale, prune_layers
+        self.alpha, self.beta, self.llr_scale, self.prune = alpha, beta, llr_scale, prune_layers
         self.llr_dtype = np.dtype(llr_dtype)
         self.dev = torch.device("cuda", device_id)
         self.device_id = device_id
@@ -44,9 +43,8 @@ class DeviceDecodeChain:
     def _codec_for(self, n_layers):
         if self._codec is None or self._codec_layers != n_layers:
             self.close()
-            a = self.alpha if self.alpha is not None else default_alpha(self.p.BG, n_layers)
             self._codec = Codec(self.p.BG, self.p.Z_c, max_iter=self.iterations, n_layers=n_layers, early_term=True,
-                                alpha=a, llr_scale=self.llr_scale, llr_dtype=self.llr_dtype, device_id=self.device_id)
+                                alpha=self.alpha or 0.0, beta=self.beta, llr_scale=self.llr_scale, llr_dtype=self.llr_dtype, device_id=self.device_id)
             self._codec_layers = n_layers
         return self._codec
 

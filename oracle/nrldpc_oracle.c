@@ -203,7 +203,8 @@ int orc_encode(int bg, int Z, const uint8_t* info, int batch, uint8_t* cw) {
 /*            (j < kb+4) -> +/-2^20 (filler "certain" bits, NRLDPCDecoder.m:264)               */
 /*   layer l, row z, edges in ascending column order, v_j = col_j*Z + (z+P_lj) mod Z :         */
 /*            t_j = APP[v_j] - r[l,j,z];  m1<=m2 two smallest |t_j|;  S = xor of (t_j<0)       */
-/*            M1 = min(127, rint(alpha*m1)), M2 = min(127, rint(alpha*m2))  (fp32, ties-even)  */
+/*            M1 = clamp(rint(alpha*m1 - beta), 0, 127), M2 likewise with m2 (one fp32 fused          */
+/*            multiply-add, then round to nearest even; beta = 0 is plain normalised min-sum)  */
 /*            r'_j = ((t_j<0)^S ? -1 : +1) * (|t_j|==m1 ? M2 : M1);  APP[v_j] = t_j + r'_j     */
 /*   stop     after an iteration if early_term and every parity of the active rows holds        */
 /*   output   hard_k = APP_k < 0 (k < K); app = APP/scale                                      */
@@ -217,7 +218,14 @@ static int32_t ingest(double llr, int scale, int core) {
     return (int32_t)nearbyintf(x);
 }
 
-static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_term, float alpha,
+static int32_t scale_mag(float alpha, float beta, int32_t m) {
+    float f = nearbyintf(fmaf(alpha, (float)m, -beta));
+    if (f > (float)ORC_QMAX) f = (float)ORC_QMAX;
+    if (f < 0.0f) f = 0.0f;
+    return (int32_t)f;
+}
+
+static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_term, float alpha, float beta,
                     const int32_t* q, uint8_t* hard, int32_t* app_q, int8_t* rmsg, int32_t* APP) {
     const int Z = g->Z;
     const int N = g->ncols * Z;
@@ -240,9 +248,7 @@ static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_te
                     if (a < m1) { m2 = m1; m1 = a; } else if (a < m2) m2 = a;
                     S ^= (t[j] < 0);
                 }
-                float f1 = nearbyintf(alpha * (float)m1), f2 = nearbyintf(alpha * (float)m2);
-                int32_t M1 = f1 > (float)ORC_QMAX ? ORC_QMAX : (int32_t)f1;
-                int32_t M2 = f2 > (float)ORC_QMAX ? ORC_QMAX : (int32_t)f2;
+                const int32_t M1 = scale_mag(alpha, beta, m1), M2 = scale_mag(alpha, beta, m2);
                 for (int j = 0; j < deg; ++j) {
                     int32_t a = t[j] < 0 ? -t[j] : t[j];
                     int32_t mag = (a == m1) ? M2 : M1;
@@ -272,8 +278,8 @@ static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_te
 
 /* llr: [batch][ncols*Z] double.  hard: [batch][K] bytes.  iters: [batch] or NULL.
  * app: [batch][ncols*Z] float (APP/scale) or NULL. */
-int orc_decode_nmsq(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, int scale,
-                    const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
+int orc_decode_onmsq(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, float beta, int scale,
+                     const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
     orc_graph g;
     int rc = graph_init(&g, bg, Z);
     if (rc) return rc;
@@ -289,7 +295,7 @@ int orc_decode_nmsq(int bg, int Z, int n_layers, int max_iter, int early_term, f
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < batch; ++b) {
             for (size_t v = 0; v < N; ++v) q[v] = ingest(llr[b * N + v], scale, (int)(v / Z) < g.kb + 4);
-            int it = nmsq_one(&g, n_layers, max_iter, early_term, alpha, q, hard + b * K, aq, rm, APP);
+            int it = nmsq_one(&g, n_layers, max_iter, early_term, alpha, beta, q, hard + b * K, aq, rm, APP);
             if (iters) iters[b] = it;
             if (app)
                 for (size_t v = 0; v < N; ++v) app[b * N + v] = (float)aq[v] / (float)scale;
@@ -299,12 +305,18 @@ int orc_decode_nmsq(int bg, int Z, int n_layers, int max_iter, int early_term, f
     return 0;
 }
 
+/* beta = 0: plain normalised min-sum (the committed golden vectors of round 1 were made with it) */
+int orc_decode_nmsq(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, int scale,
+                    const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
+    return orc_decode_onmsq(bg, Z, n_layers, max_iter, early_term, alpha, 0.0f, scale, llr, batch, hard, iters, app);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* REFERENCE semantics: flooding sum-product in double, stop when H*c = 0                      */
 /* (comm.LDPCDecoder as configured at NRLDPCDecoder.m:120; +inf fillers, 0 punctured, :262-264) */
 /* ------------------------------------------------------------------------------------------ */
 static int bp_one(const orc_graph* g, int n_layers, int max_iter, const double* lam, uint8_t* hard,
-                  double* r, double* APP) {
+                  double* r, double* APP, double* app_out) {
     const int Z = g->Z, N = g->ncols * Z;
     const int ne = g->row_ptr[n_layers];
     for (size_t i = 0; i < (size_t)ne * Z; ++i) r[i] = 0.0;
@@ -356,11 +368,14 @@ static int bp_one(const orc_graph* g, int n_layers, int max_iter, const double* 
     }
     if (it > max_iter) it = max_iter;
     for (int k = 0; k < g->kb * Z; ++k) hard[k] = APP[k] < 0;
+    if (app_out) memcpy(app_out, APP, sizeof(double) * (size_t)N);
     return it;
 }
 
-int orc_decode_bp_flood(int bg, int Z, int n_layers, int max_iter, const double* llr, int batch,
-                        uint8_t* hard, int32_t* iters, int nthreads) {
+/* app (nullable): a-posteriori LLRs [batch][ncols*Z] after the last sweep (comm.LDPCDecoder's
+ * 'DecisionMethod','Soft decision' output; the reference uses hard decisions only). */
+int orc_decode_bp_flood_app(int bg, int Z, int n_layers, int max_iter, const double* llr, int batch,
+                            uint8_t* hard, int32_t* iters, int nthreads, double* app) {
     orc_graph g;
     int rc = graph_init(&g, bg, Z);
     if (rc) return rc;
@@ -382,12 +397,17 @@ int orc_decode_bp_flood(int bg, int Z, int n_layers, int max_iter, const double*
                 double x = llr[b * N + v];
                 lam[v] = (x != x) ? 0.0 : x;
             }
-            int it = bp_one(&g, n_layers, max_iter, lam, hard + b * K, r, APP);
+            int it = bp_one(&g, n_layers, max_iter, lam, hard + b * K, r, APP, app ? app + b * N : NULL);
             if (iters) iters[b] = it;
         }
         free(r); free(APP); free(lam);
     }
     return 0;
+}
+
+int orc_decode_bp_flood(int bg, int Z, int n_layers, int max_iter, const double* llr, int batch,
+                        uint8_t* hard, int32_t* iters, int nthreads) {
+    return orc_decode_bp_flood_app(bg, Z, n_layers, max_iter, llr, batch, hard, iters, nthreads, NULL);
 }
 
 void orc_set_threads(int n) {

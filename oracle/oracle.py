@@ -33,7 +33,9 @@ def lib():
         L.orc_syndrome_weight.argtypes = [i32, i32, i32, P]
         L.orc_encode.argtypes = [i32, i32, P, i32, P]
         L.orc_decode_nmsq.argtypes = [i32, i32, i32, i32, i32, f32, i32, P, i32, P, P, P]
+        L.orc_decode_onmsq.argtypes = [i32, i32, i32, i32, i32, f32, f32, i32, P, i32, P, P, P]
         L.orc_decode_bp_flood.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32]
+        L.orc_decode_bp_flood_app.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32, P]
         L.orc_set_threads.argtypes = [i32]
         L.orc_rate_recover.argtypes = [i32] * 9 + [P, P, i32, P, P]
         L.orc_crc.argtypes = [C.c_uint32, i32, P, i32]
@@ -76,28 +78,30 @@ def encode(bg, Z, info):
     return cw
 
 
-def decode_nmsq(bg, Z, llr, max_iter, n_layers=0, early_term=False, alpha=0.75, scale=8, want_app=False):
+def decode_nmsq(bg, Z, llr, max_iter, n_layers=0, early_term=False, alpha=0.75, scale=8, want_app=False, beta=0.0):
+    """Layered offset-normalised min-sum on the fixed-point grid; beta is in grid units (LLR * scale)."""
     rows, cols, kb = BG_DIMS[bg]
     llr = np.ascontiguousarray(llr, np.float64).reshape(-1, cols * Z)
     B = llr.shape[0]
     hard = np.zeros((B, kb * Z), np.uint8)
     iters = np.zeros(B, np.int32)
     app = np.zeros((B, cols * Z), np.float32) if want_app else None
-    rc = lib().orc_decode_nmsq(bg, Z, n_layers, max_iter, int(early_term), alpha, scale, _p(llr), B,
-                               _p(hard), _p(iters), _p(app))
+    rc = lib().orc_decode_onmsq(bg, Z, n_layers, max_iter, int(early_term), alpha, beta, scale, _p(llr), B,
+                                _p(hard), _p(iters), _p(app))
     assert rc == 0, rc
     return (hard, iters, app) if want_app else (hard, iters)
 
 
-def decode_bp_flood(bg, Z, llr, max_iter, n_layers=0, nthreads=0):
+def decode_bp_flood(bg, Z, llr, max_iter, n_layers=0, nthreads=0, want_app=False):
     rows, cols, kb = BG_DIMS[bg]
     llr = np.ascontiguousarray(llr, np.float64).reshape(-1, cols * Z)
     B = llr.shape[0]
     hard = np.zeros((B, kb * Z), np.uint8)
     iters = np.zeros(B, np.int32)
-    rc = lib().orc_decode_bp_flood(bg, Z, n_layers, max_iter, _p(llr), B, _p(hard), _p(iters), nthreads)
+    app = np.zeros((B, cols * Z), np.float64) if want_app else None
+    rc = lib().orc_decode_bp_flood_app(bg, Z, n_layers, max_iter, _p(llr), B, _p(hard), _p(iters), nthreads, _p(app))
     assert rc == 0, rc
-    return hard, iters
+    return (hard, iters, app) if want_app else (hard, iters)
 
 
 def rate_recover(Z, C_, K, K_prime, N, N_cb, k_0, Q_m, G, E_r, g_tilde, harq=None):

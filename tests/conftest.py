@@ -42,3 +42,9 @@ def awgn_llr(rng, cw, esn0_db, dtype, Z, E=None):
     if E is not None:
         llr[:, 2 * Z + E:] = 0
     return llr.astype(dtype)
+
+
+def rule_kw(codec, scale=8):
+    """The check-node rule a Codec resolved (cfg.alpha == 0 -> nrldpc_default_rule) as oracle keyword arguments:
+    the C ABI takes beta in LLR units, the oracle in grid units (LLR * scale)."""
+    return {"alpha": codec.alpha, "beta": codec.beta * scale}

@@ -5,24 +5,28 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALL_Z, BG_DIMS, awgn_llr
+from conftest import ALL_Z, BG_DIMS, awgn_llr, rule_kw
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def run_case(pkg, orc, rng, bg, Z, B, esn0, iters, nl=0, et=True, dt=np.float16, alpha=0.75, scale=8, app=True):
+def run_case(pkg, orc, rng, bg, Z, B, esn0, iters, nl=0, et=True, dt=np.float16, alpha=None, scale=8, app=True, beta=0.0):
+    """alpha None: the library's own rule for (bg, nl) (cfg.alpha = 0); beta in LLR units as in nrldpc_cfg."""
     kb = BG_DIMS[bg][2]
     info = rng.integers(0, 2, (B, kb * Z), dtype=np.uint8)
     cw = orc.encode(bg, Z, info)
     llr = awgn_llr(rng, cw, esn0, dt, Z)
-    c = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, alpha=alpha, llr_scale=scale, llr_dtype=dt)
+    c = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, alpha=alpha or 0.0, beta=beta, llr_scale=scale,
+                  llr_dtype=dt)
     try:
         out = c.decode(llr, want_iters=True, want_app=app)
     finally:
         c.close()
-    ref = orc.decode_nmsq(bg, Z, llr.astype(np.float64), iters, n_layers=nl, early_term=et, alpha=alpha,
-                          scale=scale, want_app=app)
+    if alpha is not None:
+        assert c.alpha == np.float32(alpha) and c.beta == np.float32(beta)
+    ref = orc.decode_nmsq(bg, Z, llr.astype(np.float64), iters, n_layers=nl, early_term=et, scale=scale, want_app=app,
+                          **rule_kw(c, scale))
     assert (out[0] == ref[0]).all(), "hard decisions differ"
     assert (out[1] == ref[1]).all(), "iteration counts differ"
     if app:
@@ -91,15 +95,36 @@ def test_per_iteration_soft_llrs(pkg, orc):
             c = pkg.Codec(bg, Z, max_iter=it, early_term=False, llr_dtype=np.float32)
             h, iters, app = c.decode(llr, want_iters=True, want_app=True)
             c.close()
-            ho, io, ao = orc.decode_nmsq(bg, Z, llr.astype(np.float64), it, early_term=False, want_app=True)
+            ho, io, ao = orc.decode_nmsq(bg, Z, llr.astype(np.float64), it, early_term=False, want_app=True, **rule_kw(c))
             assert (app == ao).all() and (h == ho).all() and (iters == it).all()
 
 
-@pytest.mark.parametrize("alpha,scale", [(0.625, 8), (0.6875, 16), (0.8, 4), (1.0, 8), (0.75, 32), (0.5, 1)])
-def test_alpha_and_scale(pkg, orc, alpha, scale):
+@pytest.mark.parametrize("alpha,scale,beta", [(0.625, 8, 0.0), (0.6875, 16, 0.0), (0.8, 4, 0.0), (1.0, 8, 0.0), (0.75, 32, 0.0),
+                                              (0.5, 1, 0.0), (0.875, 8, 0.375), (0.8125, 8, 0.25), (1.0, 16, 0.5),
+                                              (0.9, 4, 0.3), (0.75, 8, 4.0)])
+def test_alpha_beta_and_scale(pkg, orc, alpha, scale, beta):
+    """Explicit check-node rules: normalisation alpha, offset beta (LLR units), grid scale."""
     rng = np.random.default_rng(int(alpha * 1000) + scale)
-    run_case(pkg, orc, rng, 1, 96, 4, 0.5, 10, alpha=alpha, scale=scale)
-    run_case(pkg, orc, rng, 2, 384, 2, 0.0, 6, alpha=alpha, scale=scale, et=False)
+    run_case(pkg, orc, rng, 1, 96, 4, 0.5, 10, alpha=alpha, scale=scale, beta=beta)
+    run_case(pkg, orc, rng, 2, 384, 2, 0.0, 6, alpha=alpha, scale=scale, et=False, beta=beta)
+    run_case(pkg, orc, rng, 1, 384, 3, -1.0, 8, alpha=alpha, scale=scale, et=False, app=False, beta=beta)  # pipelined build
+
+
+def test_default_rule_lives_in_the_c_abi(pkg):
+    """cfg.alpha = 0 resolves to nrldpc_default_rule(bg, n_layers) inside nrldpc_create: a MEX gateway that passes
+    no rule gets the same decoder as the Python mirror (the ABI used to fall back to alpha = 0.75)."""
+    for bg, rows in ((1, 46), (2, 42)):
+        for nl in (0, 4, 5, 7, 12, 13, 22, 24, 32, rows):
+            a, b = pkg.default_rule(bg, nl)
+            c = pkg.Codec(bg, 384, max_iter=2, n_layers=nl)
+            assert (c.alpha, c.beta) == (a, b) and 0.5 <= a <= 1.0 and 0.0 <= b <= 1.0
+            c.close()
+    c = pkg.Codec(1, 384, max_iter=2, alpha=0.75)
+    assert (c.alpha, c.beta) == (0.75, 0.0)  # an explicit alpha keeps plain normalised min-sum unless beta is given
+    c.close()
+    for bad in (dict(alpha=1.5), dict(alpha=-0.5), dict(alpha=0.75, beta=-1.0), dict(alpha=0.75, beta=9.0)):
+        with pytest.raises(pkg.UnsupportedParameters):
+            pkg.Codec(1, 384, max_iter=2, **bad)
 
 
 def test_special_llr_values(pkg, orc):
@@ -122,7 +147,7 @@ def test_special_llr_values(pkg, orc):
         h, it, app = c.decode(llr.astype(dt), want_iters=True, want_app=True)
         c.close()
         ho, io, ao = orc.decode_nmsq(bg, Z, llr.astype(dt).astype(np.float64), 10, n_layers=12, early_term=True,
-                                     want_app=True)
+                                     want_app=True, **rule_kw(c))
         assert (h == ho).all() and (it == io).all() and (app == ao).all()
         assert (h[0] == info[0]).all() and it[4] == 1 and not h[4].any()
 
@@ -139,7 +164,8 @@ def test_randomised_configurations(pkg, orc):
         run_case(pkg, orc, rng, bg, Z, int(rng.integers(1, 7)), float(rng.uniform(-2.0, 8.0)), int(rng.integers(1, 13)),
                  nl=nl, et=bool(rng.integers(0, 2)), dt=[np.float16, np.float32][int(rng.integers(0, 2))],
                  alpha=float(rng.choice([0.5, 0.625, 0.6875, 0.75, 0.8, 0.875, 1.0])),
-                 scale=int(rng.choice([2, 4, 8, 16])), app=bool(rng.integers(0, 2)))
+                 scale=int(rng.choice([2, 4, 8, 16])), app=bool(rng.integers(0, 2)),
+                 beta=float(rng.choice([0.0, 0.0, 0.125, 0.25, 0.375, 0.5, 0.7])))
 
 
 def test_golden_fixture_on_gpu(pkg):
@@ -185,7 +211,7 @@ def test_device_pointer_entry_and_timing(pkg, orc):
         c.decode_dev(d_llr.data_ptr(), B, d_hard.data_ptr(), d_it.data_ptr(), None, s.cuda_stream)
     ms = c.last_kernel_ms()
     s.synchronize()
-    ho, io = orc.decode_nmsq(bg, Z, llr.astype(np.float64), 10, early_term=True)
+    ho, io = orc.decode_nmsq(bg, Z, llr.astype(np.float64), 10, early_term=True, **rule_kw(c))
     assert (d_hard.cpu().numpy() == ho).all() and (d_it.cpu().numpy() == io).all()
     assert 0.0 < ms < 1000.0
     c.close()

@@ -4,7 +4,7 @@ device entry points, oracle spot checks on a sample, and the mixed-(BG,Z) config
 import numpy as np
 import pytest
 
-from conftest import ALL_Z, BG_DIMS, awgn_llr
+from conftest import rule_kw, ALL_Z, BG_DIMS, awgn_llr
 
 pytestmark = pytest.mark.gpu
 
@@ -12,8 +12,7 @@ pytestmark = pytest.mark.gpu
 def _roundtrip(pkg, orc, bg, Z, B, nl, E, esn0, iters, et, seed):
     rng = np.random.default_rng(seed)
     kb = BG_DIMS[bg][2]
-    c = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, llr_dtype=np.float16,
-                  alpha=pkg.default_alpha(bg, nl or BG_DIMS[bg][0]))
+    c = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, llr_dtype=np.float16)
     info = rng.integers(0, 2, (B, kb * Z), dtype=np.uint8)
     cw = c.encode(info)
     llr = awgn_llr(rng, cw, esn0, np.float16, Z, E=E)
@@ -22,7 +21,7 @@ def _roundtrip(pkg, orc, bg, Z, B, nl, E, esn0, iters, et, seed):
     bler = float((hard != info).any(1).mean())
     sample = rng.choice(B, 6, replace=False)
     ho, io = orc.decode_nmsq(bg, Z, llr[sample].astype(np.float64), iters, n_layers=nl, early_term=et,
-                             alpha=pkg.default_alpha(bg, nl or BG_DIMS[bg][0]))
+                             **rule_kw(c))  # the library's rule for this rate (cfg.alpha = 0)
     assert (hard[sample] == ho).all() and (it[sample] == io).all()
     assert all(orc.syndrome_weight(bg, Z, cw[b]) == 0 for b in sample)
     return bler, it

@@ -25,7 +25,7 @@ def test_encoder_parity_all_Z(orc, bg):
     assert orc.syndrome_weight(bg, 8, np.zeros(BG_DIMS[bg][1] * 8, np.uint8)) == 0
 
 
-def nmsq_numpy(bg, Z, llr, max_iter, n_layers, early_term, alpha, scale, orc):
+def nmsq_numpy(bg, Z, llr, max_iter, n_layers, early_term, alpha, scale, orc, beta=0.0):
     """Independent restatement of NMS-Q (vectorised over z, written from the algorithm statement in
     DESIGN.md, not from the C code)."""
     nrows, ncols, kb = BG_DIMS[bg]
@@ -48,8 +48,10 @@ def nmsq_numpy(bg, Z, llr, max_iter, n_layers, early_term, alpha, scale, orc):
             srt = np.sort(a, axis=0)
             m1, m2 = srt[0], srt[1]
             S = (t < 0).sum(0) & 1
-            M1 = np.minimum(np.rint(np.float32(alpha) * m1.astype(np.float32)), 127).astype(np.int64)
-            M2 = np.minimum(np.rint(np.float32(alpha) * m2.astype(np.float32)), 127).astype(np.int64)
+            # one fused multiply-add in fp32 = the exact product minus beta, rounded once to fp32 (float64 holds
+            # alpha*m - beta exactly: 24-bit alpha x 21-bit m), then round half to even, then clamp to [0, 127]
+            fm = lambda m: np.clip(np.rint((np.float64(np.float32(alpha)) * m - np.float64(np.float32(beta))).astype(np.float32)), 0, 127).astype(np.int64)
+            M1, M2 = fm(m1), fm(m2)
             for k, (e, v) in enumerate(zip(es, vidx)):
                 mag = np.where(a[k] == m1, M2, M1)
                 rr = np.where(((t[k] < 0) ^ (S == 1)), -mag, mag)
@@ -68,10 +70,11 @@ def nmsq_numpy(bg, Z, llr, max_iter, n_layers, early_term, alpha, scale, orc):
     return (APP[: kb * Z] < 0).astype(np.uint8), it_done, (APP / scale).astype(np.float32)
 
 
-@pytest.mark.parametrize("bg,Z,nl,et,alpha,scale,esn0", [
-    (1, 8, 0, False, 0.75, 8, 1.0), (1, 24, 10, True, 0.625, 16, 3.0), (2, 20, 0, True, 0.75, 8, 0.0),
-    (2, 6, 6, False, 0.8125, 4, 4.0), (1, 36, 46, True, 0.6875, 8, -1.0)])
-def test_nmsq_c_vs_numpy(orc, bg, Z, nl, et, alpha, scale, esn0):
+@pytest.mark.parametrize("bg,Z,nl,et,alpha,scale,esn0,beta", [
+    (1, 8, 0, False, 0.75, 8, 1.0, 0.0), (1, 24, 10, True, 0.625, 16, 3.0, 0.0), (2, 20, 0, True, 0.75, 8, 0.0, 0.0),
+    (2, 6, 6, False, 0.8125, 4, 4.0, 0.0), (1, 36, 46, True, 0.6875, 8, -1.0, 0.0),
+    (1, 36, 46, True, 0.875, 8, -1.0, 3.0), (2, 20, 0, True, 0.8125, 8, 0.0, 2.0), (1, 8, 0, False, 0.7, 16, 1.0, 2.3)])
+def test_nmsq_c_vs_numpy(orc, bg, Z, nl, et, alpha, scale, esn0, beta):
     rng = np.random.default_rng(7)
     kb = BG_DIMS[bg][2]
     info = rng.integers(0, 2, (3, kb * Z), dtype=np.uint8)
@@ -80,11 +83,92 @@ def test_nmsq_c_vs_numpy(orc, bg, Z, nl, et, alpha, scale, esn0):
     llr[0, 5 * Z + 1] = np.inf
     llr[1, 3 * Z] = np.nan
     llr[2, (kb + 5) * Z] = -np.inf
-    h, it, app = orc.decode_nmsq(bg, Z, llr, 6, n_layers=nl, early_term=et, alpha=alpha, scale=scale, want_app=True)
+    h, it, app = orc.decode_nmsq(bg, Z, llr, 6, n_layers=nl, early_term=et, alpha=alpha, scale=scale, want_app=True,
+                                 beta=beta)
     for b in range(3):
-        hn, itn, appn = nmsq_numpy(bg, Z, llr[b], 6, nl, et, alpha, scale, orc)
+        hn, itn, appn = nmsq_numpy(bg, Z, llr[b], 6, nl, et, alpha, scale, orc, beta)
         assert (h[b] == hn).all() and it[b] == itn
         assert (app[b] == appn).all()
+
+
+def bp_flood_numpy(bg, Z, llr, max_iter, n_layers, orc):
+    """Independent restatement of the reference-semantics decoder, written from SURVEY.md appendix B1 (not from
+    the C code): flooding sum-product in double, r_cv = 2 atanh(prod_{v' != v} tanh(q_v'c / 2)) with the product
+    clipped to +-(1 - 1e-15), q_vc = lambda_v + sum_{c' != c} r_c'v, stop when every parity check holds
+    ('Parity check satisfied', NRLDPCDecoder.m:120).  Leave-one-out products are formed directly per edge."""
+    nrows, ncols, kb = BG_DIMS[bg]
+    n_layers = n_layers or nrows
+    r_, c_, s_ = orc.graph_edges(bg, Z)
+    zz = np.arange(Z)
+    lam = np.where(np.isnan(llr), 0.0, np.asarray(llr, np.float64))
+    rows = [[(e, c_[e] * Z + (zz + s_[e]) % Z) for e in np.nonzero(r_ == l)[0]] for l in range(n_layers)]
+    r = {e: np.zeros(Z) for row in rows for e, _ in row}
+
+    def totals():
+        a = lam.copy()
+        for row in rows:
+            for e, v in row:
+                a[v] += r[e]
+        return a
+
+    it_done = max_iter
+    with np.errstate(invalid="ignore"):
+        for it in range(1, max_iter + 1):
+            app = totals()
+            new = {}
+            for row in rows:
+                q = [np.where(np.isinf(app[v]), app[v], app[v] - r[e]) for e, v in row]
+                th = [np.tanh(0.5 * x) for x in q]
+                for k, (e, v) in enumerate(row):
+                    p = np.ones(Z)
+                    for k2 in range(len(row)):
+                        if k2 != k:
+                            p = p * th[k2]
+                    new[e] = 2.0 * np.arctanh(np.clip(p, -(1 - 1e-15), 1 - 1e-15))
+            r = new
+            app = totals()
+            bad = 0
+            for row in rows:
+                par = np.zeros(Z, np.int64)
+                for e, v in row:
+                    par ^= (app[v] < 0)
+                bad += int(par.sum())
+            if bad == 0:
+                it_done = it
+                break
+    return (app[: kb * Z] < 0).astype(np.uint8), it_done, app
+
+
+@pytest.mark.parametrize("bg,Z,nl,esn0,iters", [(2, 20, 12, 1.0, 10), (1, 8, 0, 0.0, 6), (2, 6, 0, 3.0, 8), (1, 24, 10, 2.5, 5),
+                                                 (1, 36, 46, -1.0, 7)])
+def test_bp_flood_c_vs_numpy(orc, bg, Z, nl, esn0, iters):
+    """The stand-in for comm.LDPCDecoder (CPU baseline, BLER yardstick) against an independent restatement:
+    hard bits and sweep counts equal at the full sweep count; a-posteriori LLRs within 1e-8 after 2 sweeps (later,
+    converged messages sit at the clip 1 - 1e-15 where one ulp of the product moves r = ln(2/eps) by up to 0.1, so
+    soft values are order-of-multiplication dependent there and are compared at 1e-2 only)."""
+    rng = np.random.default_rng(17)
+    kb = BG_DIMS[bg][2]
+    info = rng.integers(0, 2, (4, kb * Z), dtype=np.uint8)
+    info[:, kb * Z - 7:] = 0
+    cw = orc.encode(bg, Z, info)
+    llr = awgn_llr(rng, cw, esn0, np.float64, Z)
+    llr[:, kb * Z - 7: kb * Z] = np.inf     # fillers (NRLDPCDecoder.m:264)
+    llr[1, 3 * Z + 1] = np.nan             # treated as 0
+    llr[2, (kb + 6) * Z:] = 0.0            # untransmitted tail
+    llr[3] *= 1.5                          # larger LLRs, short of saturating tanh in double
+    h, it, app = orc.decode_bp_flood(bg, Z, llr, iters, n_layers=nl, want_app=True)
+    for b in range(4):
+        hn, itn, appn = bp_flood_numpy(bg, Z, llr[b], iters, nl, orc)
+        assert it[b] == itn and (h[b] == hn).all()
+        fin = np.isfinite(appn)
+        assert (np.isinf(app[b]) == ~fin).all() and (app[b][~fin] == appn[~fin]).all()
+        assert np.allclose(app[b][fin], appn[fin], rtol=1e-2, atol=1e-2)
+    h2, it2, app2 = orc.decode_bp_flood(bg, Z, llr, 2, n_layers=nl, want_app=True)
+    for b in range(4):
+        hn, itn, appn = bp_flood_numpy(bg, Z, llr[b], 2, nl, orc)
+        fin = np.isfinite(appn)
+        assert it2[b] == itn and (h2[b] == hn).all()
+        assert np.allclose(app2[b][fin], appn[fin], rtol=1e-8, atol=1e-8)
 
 
 @pytest.mark.parametrize("bg,Z", [(1, 384), (2, 384), (1, 2), (2, 3), (1, 208), (2, 20)])

@@ -32,8 +32,7 @@ def synth(codec, bg, Z, B, E, esn0, seed):
 
 def run(name, bg, Z, B, E, nl, iters, et, esn0, reps=5):
     rows, cols, kb = DIMS[bg]
-    codec = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, alpha=pkg.default_alpha(bg, nl or rows),
-                      llr_dtype=np.float16)
+    codec = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=et, llr_dtype=np.float16)
     info, llr = synth(codec, bg, Z, B, E, esn0, 1234)
     hard = torch.empty((B, kb * Z), device="cuda", dtype=torch.uint8)
     its = torch.empty(B, device="cuda", dtype=torch.int32)

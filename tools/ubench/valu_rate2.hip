@@ -53,7 +53,22 @@ template <int OP> __global__ __launch_bounds__(256) void k(uint32_t* out, int it
         else if constexpr (OP == 41) asm volatile("v_mul_f32 %0, 0x3f400000, %0" : "+v"(r)); \
         else if constexpr (OP == 42) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(b)); \
         else if constexpr (OP == 43) asm volatile("v_sad_u32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(b)); \
-        else if constexpr (OP == 44) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r) : "v"(c));
+        else if constexpr (OP == 44) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 45) asm volatile("v_sub_f32_e64 %0, %1, |%0| clamp" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 46) asm volatile("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 47) asm volatile("v_cvt_f32_ubyte3 %0, %0" : "+v"(r)); \
+        else if constexpr (OP == 48) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 49) asm volatile("v_min_u32 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 50) asm volatile("v_max_u32 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 51) asm volatile("v_min_i32 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 52) asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 53) asm volatile("v_cmp_eq_f32 vcc, |%0|, %1" : : "v"(r), "v"(c) : "vcc"); \
+        else if constexpr (OP == 54) asm volatile("v_add_f32_e64 %0, %0, %1 clamp" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 55) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(r)); \
+        else if constexpr (OP == 56) asm volatile("v_sub_u16 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 57) asm volatile("v_pk_sub_i16 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 58) asm volatile("v_med3_i16 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 59) asm volatile("v_min_i16 %0, %1, %0" : "+v"(r) : "v"(c));
         REP8(ONE(a0) ONE(a1) ONE(a2) ONE(a3) ONE(a4) ONE(a5) ONE(a6) ONE(a7))
     }
     f2 ps = pa0 + pa1 + pa2 + pa3 + pa4 + pa5 + pa6 + pa7;
@@ -117,6 +132,21 @@ int main() {
     run<41>("v_mul_f32 x0.75 inline?", d, blocks, it);
     run<42>("v_med3_i32", d, blocks, it);
     run<43>("v_sad_u32", d, blocks, it);
-    run<44>("v_cvt_pk_i16_f32?", d, blocks, it);
+    run<44>("v_cvt_pkrtz_f16_f32", d, blocks, it);
+    run<45>("v_sub_f32 e64 |x| clamp", d, blocks, it);
+    run<46>("v_cvt_pk_u8_f32", d, blocks, it);
+    run<47>("v_cvt_f32_ubyte3", d, blocks, it);
+    run<48>("v_fma_f32 (3 vgpr)", d, blocks, it);
+    run<49>("v_min_u32", d, blocks, it);
+    run<50>("v_max_u32", d, blocks, it);
+    run<51>("v_min_i32", d, blocks, it);
+    run<52>("v_med3_u32", d, blocks, it);
+    run<53>("v_cmp_eq_f32 |x|", d, blocks, it);
+    run<54>("v_add_f32 e64 clamp", d, blocks, it);
+    run<55>("v_cvt_f32_ubyte0", d, blocks, it);
+    run<56>("v_sub_u16", d, blocks, it);
+    run<57>("v_pk_sub_i16", d, blocks, it);
+    run<58>("v_med3_i16", d, blocks, it);
+    run<59>("v_min_i16", d, blocks, it);
     return 0;
 }
