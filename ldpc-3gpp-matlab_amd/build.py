@@ -19,6 +19,8 @@ Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
 Z64_BG1 = (60, 64, 104, 112, 120, 128, 144, 176, 192, 208, 224, 240, 256, 288, 320, 352, 384)
 Z64_BG2 = (52, 60, 64, 88, 96, 104, 112, 120, 128, 144, 192, 208, 224, 240, 256, 288, 320, 352, 384)
 Z64_PAIRS = [(1, z) for z in Z64_BG1] + [(2, z) for z in Z64_BG2]
+# = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
+Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7)]
 HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_wave.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
@@ -53,6 +55,8 @@ def build_lib(force=False, verbose=False, jobs=None):
     units = [(os.path.join(CSRC, f), os.path.join(OBJDIR, f.replace(".hip", ".o")), []) for f in SOURCES]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d.o" % (bg, z)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64_PAIRS]
+    units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
+               ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64_NL]
     newest = max(os.path.getmtime(d) for d in _deps())
 
     def compile_one(u):

@@ -69,7 +69,11 @@ template <int BG, int ZC, int NCWG> constexpr int z64_wpe() {
     return BG == 2 ? 6 : (z64_nwv(ZC) == 8 || z64_nwv(ZC) == 5 || z64_nwv(ZC) == 4 || z64_nwv(ZC) == 3) ? 4 : 3;
 }
 
-template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>()> struct Z64 : BGD<BG> {
+// NL: active layers (rows 0..NL-1) when that count is a compile-time fact (all rows, or one of the pruned counts the
+// pipelined kernels are instantiated for); only the mirror-coherence analysis depends on it.
+template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROWS> struct Z64 : BGD<BG> {
+    static constexpr int NL = NL_;
+    static constexpr int NNZA = BGD<BG>::row_ptr(NL_); // edges of the active rows
     static constexpr int BLK = z64_blk(ZC);             // rows (ring words) per wave
     static_assert(BLK >= 4 && ZC % BLK == 0, "no usable block size for this lifting size");
     static constexpr int NWV = ZC / BLK;                // waves per codeword
@@ -87,7 +91,7 @@ template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>()> struct Z64 : BGD<BG> {
     // mirror ("B") if kb' > kb_e, none if equal.
     static constexpr int next_on_column(int e) {
         const int c = BGD<BG>::col(e);
-        for (int i = e + 1; i < BGD<BG>::NNZ; ++i)
+        for (int i = e + 1; i < NNZA; ++i)
             if (BGD<BG>::col(i) == c) return i;
         for (int i = 0; i < e; ++i)
             if (BGD<BG>::col(i) == c) return i;
@@ -119,8 +123,8 @@ template <int LO, int HI, class F> __device__ __forceinline__ void dispatch_w(in
 
 // One base-graph layer for this thread's check row, split into phases so that the layers of a
 // column-disjoint barrier group can issue all their LDS reads first and share one mirror dispatch.
-template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
-    using G = Z64<BG, ZC>;
+template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct LayerZ64 {
+    using G = Z64<BG, ZC, z64_ncwg<BG, ZC>(), NL>;
     static constexpr int e0 = G::row_ptr(L);
     static constexpr int deg = G::row_ptr(L + 1) - e0;
     static constexpr bool HAS_EXT = (L >= 4);
@@ -141,7 +145,7 @@ template <int BG, int ZC, int L, bool FULL> struct LayerZ64 {
     // barrier group in front of this layer's group (cyclically), otherwise "early": early edges may be read
     // and folded into the min search BEFORE the barrier that separates the two groups.
     static constexpr unsigned long long prev_written() {
-        using LG = LayerGroups<BG>;
+        using LG = LayerGroups<BG, NL>;
         return LG::group_mask((LG::group_index(L) + LG::ngroups() - 1) % LG::ngroups());
     }
     static constexpr bool is_late(int j) { return (prev_written() >> G::col(e0 + j)) & 1ull; }
@@ -335,15 +339,15 @@ __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uin
 
 // ---- software pipeline over barrier groups (FULL && PLAIN kernels) -------------------------------------
 // Group gi's layers; `early` = loads + min search over the edges that do not depend on the previous group.
-template <int BG, int ZC, int GI> struct GroupZ64 {
-    using LG = LayerGroups<BG>;
+template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS> struct GroupZ64 {
+    using LG = LayerGroups<BG, NL>;
     static constexpr int GS = LG::group_first(GI);
     static constexpr int N = LG::group_last(GS) - GS + 1;
     static_assert(N >= 1 && N <= 3, "group size");
     struct NoLayer {}; // absent second / third layer: no storage, so copying a group copies only live state
-    LayerZ64<BG, ZC, GS, true> l0;
-    std::conditional_t<(N > 1), LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true>, NoLayer> l1;
-    std::conditional_t<(N > 2), LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true>, NoLayer> l2;
+    LayerZ64<BG, ZC, GS, true, NL> l0;
+    std::conditional_t<(N > 1), LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true, NL>, NoLayer> l1;
+    std::conditional_t<(N > 2), LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true, NL>, NoLayer> l2;
 
     template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
         l0.template load_part<LATE>(lds, R);
@@ -380,16 +384,16 @@ template <int BG, int ZC, int GI> struct GroupZ64 {
 // Returns (through `next0`) group 0 with its early part done for the following iteration.
 // ET: also record the sign of every extension-parity bit's a-posteriori value (the parity pass of the
 // early-termination kernel needs it).
-template <int BG, int ZC, int GI, bool ET = false>
-__device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI>& cur, GroupZ64<BG, ZC, 0>& next0, DecState<BG>& st,
+template <int BG, int ZC, int GI, bool ET = false, int NL = BGT<BG>::ROWS>
+__device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, GroupZ64<BG, ZC, 0, NL>& next0, DecState<BG>& st,
                                              char* lds, const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB,
                                              int w, const DecArgs& a, float cap, uint32_t& esign_lo,
                                              uint32_t& esign_hi) {
-    constexpr int NG = LayerGroups<BG>::ngroups();
+    constexpr int NG = LayerGroups<BG, NL>::ngroups();
     __syncthreads(); // ends group GI-1 (for GI == 0: the previous iteration / the prologue)
     cur.template loads<true>(lds, R);
     if constexpr (GI + 1 < NG) {
-        GroupZ64<BG, ZC, GI + 1> nxt;
+        GroupZ64<BG, ZC, GI + 1, NL> nxt;
         nxt.template loads<false>(lds, R); // columns untouched by group GI: safe before its writes
         cur.template track<true>(st, cap);
         cur.finish(st, lds, R, a);
@@ -401,7 +405,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI>& cur, GroupZ64
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
         }
         nxt.template track<false>(st, cap);
-        pipeline_z64<BG, ZC, GI + 1, ET>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+        pipeline_z64<BG, ZC, GI + 1, ET, NL>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
     } else {
         next0.template loads<false>(lds, R);
         cur.template track<true>(st, cap);
@@ -440,11 +444,15 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
 //        per-thread `done` predicate, no extension-bit bookkeeping, no parity pass.
 // ETP  : FULL with early termination (no soft output): the pipelined iteration of PLAIN plus the sign of every
 //        extension-parity bit, then the parity pass; a finished codeword's waves only keep the barriers.
-template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false>
+// NL   : the compile-time layer count of a FULL build: all rows, or one of the pruned counts of NRLDPC_Z64_NL_LIST
+//        (the rate-matching points BASELINE.json names), each with its own barrier-group table and prefetch plan.
+template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false, int NL = BGT<BG>::ROWS>
 __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_decode_z64_kernel(const DecArgs a) {
     static_assert(!PLAIN || FULL, "PLAIN implies FULL");
     static_assert(!ETP || (FULL && !PLAIN), "ETP implies FULL and excludes PLAIN");
-    using G = Z64<BG, ZC, NCWG>;
+    static_assert(FULL || NL == BGT<BG>::ROWS, "a run-time layer count uses the all-rows tables");
+    using G = Z64<BG, ZC, NCWG, NL>;
+    using LGN = LayerGroups<BG, NL>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -534,11 +542,11 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
             // The extension-parity LLR of a pruned row is never used (only soft output echoes it): at R = 8/9
             // that is 41 of 68 columns of HBM input saved.  Blocks of 8 rows, wave-uniform branches.
             float x[G::NEXT];
-            const int next_used = (FULL || a.app) ? G::NEXT : launder(a.n_layers) - 4;
+            const int next_used = a.app ? G::NEXT : FULL ? NL - 4 : launder(a.n_layers) - 4;
             static_for<(G::NEXT + 7) / 8>([&](auto bc) {
                 constexpr int i0 = decltype(bc)::value * 8;
                 constexpr int i1 = i0 + 8 < G::NEXT ? i0 + 8 : G::NEXT;
-                if (FULL || i0 < next_used) {
+                if ((FULL && NL == G::ROWS) || i0 < next_used) {
                     static_for<i1 - i0>([&](auto ic) {
                         constexpr int i = i0 + decltype(ic)::value;
                         const size_t gi = base + (size_t)(G::NC + i) * ZC + z;
@@ -566,17 +574,17 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
         // fixed-iteration path: barrier groups software-pipelined (see pipeline_z64)
         if (active) {
             const float cap = (127.49f + a.beta) / a.alpha; // see track_part
-            GroupZ64<BG, ZC, 0> g0;
+            GroupZ64<BG, ZC, 0, NL> g0;
             g0.template loads<false>(lds, R);
             g0.template track<false>(st, cap);
             for (int it = 1; it <= a.max_iter; ++it) {
-                GroupZ64<BG, ZC, 0> nx;
-                pipeline_z64<BG, ZC, 0>(g0, nx, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+                GroupZ64<BG, ZC, 0, NL> nx;
+                pipeline_z64<BG, ZC, 0, false, NL>(g0, nx, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
                 g0 = nx;
             }
         } else {
             for (int it = 1; it <= a.max_iter; ++it)
-                for (int g = 0; g < LayerGroups<BG>::ngroups(); ++g) __syncthreads();
+                for (int g = 0; g < LGN::ngroups(); ++g) __syncthreads();
         }
         __syncthreads();
     }
@@ -592,9 +600,9 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
             // far from convergence the pass costs ~19 LDS reads per thread instead of all 274.
             uint32_t bad = 0;
             bool stop = false; // wave-uniform
-            static_for<G::ROWS>([&](auto lc) {
+            static_for<NL>([&](auto lc) {
                 constexpr int L = decltype(lc)::value;
-                if (!stop && L < launder(a.n_layers)) {
+                if (!stop && (FULL || L < launder(a.n_layers))) {
                     bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
                     if constexpr (L < 4 || (L % 4) == 3) stop = __any((int)bad) != 0;
                 }
@@ -618,13 +626,13 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
         int it = 1;
         bool all_done = false;
         if (active) {
-            GroupZ64<BG, ZC, 0> g0;
+            GroupZ64<BG, ZC, 0, NL> g0;
             g0.template loads<false>(lds, R);
             g0.template track<false>(st, cap);
             for (; it <= a.max_iter; ++it) {
                 esign_lo = 0; esign_hi = 0;
-                GroupZ64<BG, ZC, 0> nx;
-                pipeline_z64<BG, ZC, 0, true>(g0, nx, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+                GroupZ64<BG, ZC, 0, NL> nx;
+                pipeline_z64<BG, ZC, 0, true, NL>(g0, nx, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
                 g0 = nx;
                 all_done = parity_pass(it);
                 if (all_done || done) { ++it; break; }
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
         if (!all_done) {
             done = true;
             for (; it <= a.max_iter; ++it) {
-                for (int g = 0; g < LayerGroups<BG>::ngroups(); ++g) __syncthreads();
+                for (int g = 0; g < LGN::ngroups(); ++g) __syncthreads();
                 if (parity_pass(it)) break;
             }
         }
@@ -696,9 +704,10 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>()))
     }
 }
 
-template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false> static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
-    using G = Z64<BG, ZC, NCWG>;
-    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL, PLAIN, ETP>;
+template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false, int NL = BGT<BG>::ROWS>
+static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
+    using G = Z64<BG, ZC, NCWG, NL>;
+    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL, PLAIN, ETP, NL>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {}; // per device: raising the dynamic-LDS limit is a slow host call, do it once
@@ -714,8 +723,23 @@ template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false> sta
     return hipGetLastError();
 }
 
+// the pipelined pair (fixed iteration count / early termination) for a compile-time pruned layer count: its own
+// translation unit (nrldpc_decode_z64_inst.hip with -DNRLDPC_Z64_NL=<count>)
+template <int BG, int ZC, int NCWG, int NL> static hipError_t launch_z64_pruned(const DecArgs& a, hipStream_t s) {
+    if (a.early_term) return launch_z64f<BG, ZC, NCWG, true, false, true, NL>(a, s);
+    return launch_z64f<BG, ZC, NCWG, true, true, false, NL>(a, s);
+}
+
 template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
-    // pruned layer counts and soft output (a test / debug feature) share the unpipelined general kernel
+    static const bool no_pruned = getenv("NRLDPC_NO_PRUNED_PIPELINE") != nullptr; // A/B against the general kernel
+    if (!a.app && !no_pruned) {
+        // layer counts of the rate-matching points BASELINE.json names have pipelined builds of their own
+#define NRLDPC_Z64_NL_CASE(bg, z, nl) \
+        if constexpr (BG == bg && ZC == z) if (a.n_layers == nl) return launch_decode_z64_##bg##_##z##_nl##nl(a, s);
+        NRLDPC_Z64_NL_LIST(NRLDPC_Z64_NL_CASE)
+#undef NRLDPC_Z64_NL_CASE
+    }
+    // other pruned layer counts and soft output (a test / debug feature) share the unpipelined general kernel
     if (a.n_layers != BGD<BG>::ROWS || a.app) return launch_z64f<BG, ZC, NCWG, false, false>(a, s);
     if (a.early_term) return launch_z64f<BG, ZC, NCWG, true, false, true>(a, s);
     return launch_z64f<BG, ZC, NCWG, true, true>(a, s);

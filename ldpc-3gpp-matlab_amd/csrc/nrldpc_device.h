@@ -40,9 +40,11 @@ template <int BG> struct BGD : BGT<BG> {
 // them back to back is exactly the sequential schedule.  From row ~20 on, consecutive rows of both base
 // graphs alternate between column 0 and column 1 and are otherwise sparse, which pairs them up: BG1 needs
 // 32 barriers per iteration instead of 46, BG2 28 instead of 42.  Groups are formed greedily in table
-// order (the processing order is NOT changed).
-template <int BG> struct LayerGroups {
+// order (the processing order is NOT changed).  NL = number of active layers (rows 0..NL-1): a pruned layer count
+// known at compile time gets its own group table, so the cyclic "next group" of the last group is group 0 again.
+template <int BG, int NL = BGT<BG>::ROWS> struct LayerGroups {
     using G = BGD<BG>;
+    static_assert(NL >= 4 && NL <= BGT<BG>::ROWS, "active layer count");
     static constexpr unsigned long long colmask(int L) {
         unsigned long long m = 0;
         for (int e = G::row_ptr(L); e < G::row_ptr(L + 1); ++e)
@@ -61,7 +63,7 @@ template <int BG> struct LayerGroups {
         Tab t{};
         int start = 0, gi = -1;
         unsigned long long acc = 0;
-        for (int l = 0; l < G::ROWS; ++l) {
+        for (int l = 0; l < NL; ++l) {
             const unsigned long long m = colmask(l);
             if (l == 0 || (acc & m)) { start = l; acc = m; ++gi; t.gfirst[gi] = l; t.gmask[gi] = 0; } else acc |= m;
             t.gstart[l] = start;
@@ -69,8 +71,8 @@ template <int BG> struct LayerGroups {
             t.gmask[gi] |= m;
         }
         t.n = gi + 1;
-        for (int l = G::ROWS - 1; l >= 0; --l)
-            t.glast[l] = (l + 1 < G::ROWS && t.gstart[l + 1] == t.gstart[l]) ? t.glast[l + 1] : l;
+        for (int l = NL - 1; l >= 0; --l)
+            t.glast[l] = (l + 1 < NL && t.gstart[l + 1] == t.gstart[l]) ? t.glast[l + 1] : l;
         return t;
     }
     static constexpr Tab T = make();

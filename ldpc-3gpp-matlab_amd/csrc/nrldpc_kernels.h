@@ -47,6 +47,14 @@ hipError_t launch_decode_multi(int bg, int llr_kind, const DecArgs* d_tab, const
 #define NRLDPC_Z64_DECL(bg, z) hipError_t launch_decode_z64_##bg##_##z(const DecArgs& a, hipStream_t stream);
 NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
 #undef NRLDPC_Z64_DECL
+// pruned layer counts with software-pipelined builds of their own (one translation unit each): the active-layer counts
+// of BASELINE.json's rate-matching sweep at BG2 Z=384 (R = 1/4 ... 2/3 -> 32, 22, 17, 12, 9, 7 rows; R = 1/5 is all 42),
+// of its BG1 Z=384 R=8/9 shard (5 rows) and of BG1 R = 2/3 and 1/2 (13, 24).  Every other count runs the general kernel.
+#define NRLDPC_Z64_NL_LIST(X) \
+    X(1, 384, 5) X(1, 384, 13) X(1, 384, 24) X(2, 384, 32) X(2, 384, 22) X(2, 384, 17) X(2, 384, 12) X(2, 384, 9) X(2, 384, 7)
+#define NRLDPC_Z64_NL_DECL(bg, z, nl) hipError_t launch_decode_z64_##bg##_##z##_nl##nl(const DecArgs& a, hipStream_t stream);
+NRLDPC_Z64_NL_LIST(NRLDPC_Z64_NL_DECL)
+#undef NRLDPC_Z64_NL_DECL
 
 struct EncArgs {
     const uint8_t* info; // [batch][kb*Z]

@@ -53,11 +53,18 @@ def test_every_lifting_size(pkg, orc, bg):
 
 @pytest.mark.parametrize("bg,Z,nl,esn0", [(1, 384, 46, -0.8), (1, 384, 5, 6.2), (1, 384, 20, 1.0), (2, 384, 42, -1.0),
                                           (2, 384, 7, 4.5), (2, 384, 22, 0.5), (1, 352, 30, 0.0), (2, 208, 21, 1.0),
-                                          (1, 64, 4, 8.0), (2, 20, 12, 2.0)])
+                                          (1, 64, 4, 8.0), (2, 20, 12, 2.0),
+                                          # every count of NRLDPC_Z64_NL_LIST: pipelined kernels of their own
+                                          (1, 384, 13, 3.0), (1, 384, 24, 1.0), (2, 384, 32, -2.8), (2, 384, 17, 0.0),
+                                          (2, 384, 12, 1.0), (2, 384, 9, 2.2),
+                                          # neighbours of those counts: the general (run-time layer count) kernel
+                                          (1, 384, 6, 6.0), (1, 384, 12, 3.0), (2, 384, 8, 3.5), (2, 384, 23, -1.0)])
 def test_rate_pruned_layers(pkg, orc, bg, Z, nl, esn0):
     rng = np.random.default_rng(Z * 100 + nl)
     run_case(pkg, orc, rng, bg, Z, 5, esn0, 12, nl=nl, et=True)
     run_case(pkg, orc, rng, bg, Z, 3, esn0, 7, nl=nl, et=False)
+    run_case(pkg, orc, rng, bg, Z, 4, esn0, 9, nl=nl, et=False, app=False)  # the fixed-iteration throughput build
+    run_case(pkg, orc, rng, bg, Z, 5, esn0, 14, nl=nl, et=True, app=False)  # ... and its early-termination twin
 
 
 @pytest.mark.parametrize("bg", [1, 2])
