@@ -139,6 +139,42 @@ def e2e_host_path(nrldpc, info_host, llr_host_f16, rule, reps=7):
     return out
 
 
+def dry_run(args, torch):
+    """The multi-rank protocol of main() with the GPU work replaced by a sleep: exercised by the CPU test suite under
+    gloo (tests/test_dist_cpu.py) so that the torch.distributed branch of this file is executed somewhere other than
+    the driver's 8-GPU run.  Prints a line marked dry_run; it carries no measurement."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.backend == "nccl" else args.backend)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
+                          "dry_run": True, "value": None, "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak"}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,9 +184,15 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024, help="codewords for the all-core CPU baselines (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-path leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-time (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="test aid for 1-GPU boxes: every rank uses device 0 (use "
+                    "with --backend gloo; RCCL refuses two ranks on one GPU)")
+    ap.add_argument("--dry-run", action="store_true", help="test aid: run the rank protocol (init, barrier, timed loop "
+                    "bracket, max-over-ranks, one JSON line) without touching a GPU; the line says dry_run and is no result")
     args = ap.parse_args()
 
     import torch
+    if args.dry_run:
+        return dry_run(args, torch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and this framework has no CPU path")
     nrldpc = importlib.import_module("ldpc-3gpp-matlab_amd")
@@ -168,6 +210,8 @@ def main():
             dist.init_process_group(args.backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

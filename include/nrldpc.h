@@ -96,6 +96,20 @@ int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t
 int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* h, const void* const* d_llr, const int32_t* batch,
                             uint8_t* const* d_hard, int32_t* const* d_iters, void* stream);
 
+/* ---- one node, several GPUs: codeword batches shard with no collective --------------------
+ * A pool owns one codec handle and one host thread per entry of device_ids (an ordinal may repeat: several logical
+ * shards on one GPU).  nrldpc_pool_decode cuts the batch into n_devices * chunks_per_device contiguous chunks and the
+ * threads pull them from a queue, so that shards which finish early under early termination (BASELINE.json
+ * configs[4]) take more chunks; results land in place, identical to one nrldpc_decode call.  cfg->device_id is
+ * ignored.  The reference decodes one code block at a time on one thread (NRLDPCDecoder.m:257-266). */
+typedef struct nrldpc_pool* nrldpc_pool_handle;
+int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t n_devices, int32_t chunks_per_device,
+                       nrldpc_pool_handle* out);
+int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out);
+/* codewords each shard (entry of device_ids) decoded in the last nrldpc_pool_decode call; counts: [n_devices] */
+int nrldpc_pool_last_split(nrldpc_pool_handle p, int32_t* counts);
+void nrldpc_pool_destroy(nrldpc_pool_handle p);
+
 /* Systematic encode.  info: [batch][K] bytes {0,1}; cw: [batch][ncols*Z] bytes {0,1} = [info;parity]
  * with H*cw = 0 (NRLDPCEncoder.m:158). */
 int nrldpc_encode(nrldpc_handle h, const uint8_t* info, int32_t batch, uint8_t* cw);
@@ -130,6 +144,19 @@ int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, i
 int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat,
                          int32_t* d_ok, int32_t* d_cb_pass, void* stream);
 
+/* The same stage with the reference's state machine (NRLDPCDecoder.m:283-316,337), for incremental redundancy
+ * (I_HARQ ~= 0) and code-block-group retransmission (CBGTI):
+ *   cbgti_flags (host, C bytes, nullable = all 1): CBGTI_flags of NRLDPC.m:471-477; a code block is taken over --
+ *       payload written to d_b_hat, pass flag set -- only when its CRC holds (C > 1) AND its flag is 1 (:304);
+ *   keep_b_hat != 0 (I_HARQ ~= 0): d_b_hat is in/out, the b_hat_buffer of :286-287,311-313 -- segments of blocks
+ *       not taken over keep what an earlier step stored; 0: those segments are zeroed (:289);
+ *   d_cb_pass (required): in/out, the sticky code_block_CRC_passed of :280,305,315 -- the caller zeroes it at
+ *       reset() (:355); d_ok[tb] = TB CRC of the resulting b_hat holds and every flag is set (:337).
+ * nrldpc_crc_check_dev is this call with no CBGTI, keep_b_hat = 0 and d_cb_pass as a plain output. */
+int nrldpc_crc_check_harq_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat,
+                              int32_t* d_ok, int32_t* d_cb_pass, const uint8_t* cbgti_flags, int32_t keep_b_hat,
+                              void* stream);
+
 /* Transmit-side counterparts (vector generation for the Monte-Carlo harness, plot_BLER_vs_SNR.m:129):
  * nrldpc_crc_attach_dev replaces crc_calculation + code_block_segmentation of the encoder
  * (NRLDPCEncoder.m:70-124): d_a [n_tb][A] bits -> d_c [n_tb*C][K] code blocks (fillers 0), ready for
@@ -155,6 +182,7 @@ int nrldpc_lifting_size(int32_t K_b, int32_t K_prime);  /* get_3gpp_lifting_size
 const char* nrldpc_strerror(int code);
 const char* nrldpc_last_error(void); /* text of the most recent failure on this thread */
 const char* nrldpc_version(void);
+const char* nrldpc_build_id(void);   /* hash of the sources this binary was built from (build.py: source_id) */
 
 #ifdef __cplusplus
 }

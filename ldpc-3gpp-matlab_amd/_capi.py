@@ -57,10 +57,11 @@ def tb_params(p):
     return t
 
 
-EXPORTS = ["nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
+EXPORTS = ["nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_check_harq_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
            "nrldpc_decode_multi_dev", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
-           "nrldpc_version"]
+           "nrldpc_version", "nrldpc_build_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
+           "nrldpc_pool_destroy"]
 
 _lib = None
 
@@ -86,9 +87,15 @@ def load():
         return _lib
     _share_hip_runtime_with_torch()
     path = _build.LIB
-    if not os.path.exists(path):
+    if os.environ.get("NRLDPC_LIB"):
+        pass  # an explicitly selected library (kernel experiments): used as it is
+    elif _build._stale():  # missing, or built from other sources than the tree holds now (content hash)
         path = _build.build_lib()
     L = C.CDLL(path)
+    L.nrldpc_build_id.restype = C.c_char_p
+    if not os.environ.get("NRLDPC_LIB") and L.nrldpc_build_id().decode() != _build.source_id():
+        raise RuntimeError("libnrldpc_hip.so (build %s) does not match the sources in the tree (%s) and could not be "
+                           "rebuilt" % (L.nrldpc_build_id().decode(), _build.source_id()))
     vp, i32 = C.c_void_p, C.c_int32
     L.nrldpc_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
     L.nrldpc_destroy.argtypes = [vp]
@@ -101,14 +108,20 @@ def load():
     L.nrldpc_encode_dev.argtypes = [vp, vp, i32, vp, vp]
     L.nrldpc_rate_recover_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, i32, vp]
     L.nrldpc_crc_check_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, vp, vp]
+    L.nrldpc_crc_check_harq_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, vp, vp, i32, vp]
     L.nrldpc_crc_attach_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp]
     L.nrldpc_rate_match_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp]
+    L.nrldpc_pool_create.argtypes = [C.POINTER(Cfg), C.POINTER(i32), i32, i32, C.POINTER(vp)]
+    L.nrldpc_pool_decode.argtypes = [vp, vp, i32, vp, vp]
+    L.nrldpc_pool_last_split.argtypes = [vp, C.POINTER(i32)]
+    L.nrldpc_pool_destroy.argtypes = [vp]
+    L.nrldpc_pool_destroy.restype = None
     L.nrldpc_set_timing.argtypes = [vp, i32]
     L.nrldpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nrldpc_set_index.argtypes = [i32]
     L.nrldpc_lifting_size.argtypes = [i32, i32]
     L.nrldpc_default_rule.argtypes = [i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    for f in ("nrldpc_strerror", "nrldpc_last_error", "nrldpc_version"):
+    for f in ("nrldpc_strerror", "nrldpc_last_error", "nrldpc_version", "nrldpc_build_id"):
         getattr(L, f).restype = C.c_char_p
     L.nrldpc_strerror.argtypes = [i32]
     _lib = L
@@ -212,6 +225,53 @@ class Codec:
         return ms.value
 
 
+class CodecPool:
+    """One node, several GPUs (nrldpc_pool_*): one handle and one host thread per entry of device_ids, the batch cut
+    into len(device_ids) * chunks_per_device chunks pulled from a queue -- no collective, results identical to one
+    Codec.decode call.  A device ordinal may repeat (several logical shards on one GPU)."""
+
+    def __init__(self, bg, Z, device_ids, chunks_per_device=3, max_iter=50, n_layers=0, early_term=True, alpha=0.0,
+                 beta=0.0, llr_scale=0, llr_dtype=np.float32):
+        L = load()
+        self._lib = L
+        self.llr_dtype = np.dtype(llr_dtype)
+        self.device_ids = [int(d) for d in device_ids]
+        cfg = Cfg(int(bg), int(Z), int(n_layers), int(max_iter), int(bool(early_term)), float(alpha), int(llr_scale),
+                  _NP2DT[self.llr_dtype], 0, 0, float(beta))
+        ids = (C.c_int32 * len(self.device_ids))(*self.device_ids)
+        self._p = C.c_void_p()
+        check(L.nrldpc_pool_create(C.byref(cfg), ids, len(self.device_ids), int(chunks_per_device), C.byref(self._p)))
+        rows, cols, kb = {1: (46, 68, 22), 2: (42, 52, 10)}[int(bg)]
+        self.K, self.N_cw = kb * int(Z), cols * int(Z)
+
+    def decode(self, llr, want_iters=False):
+        llr = np.ascontiguousarray(llr, self.llr_dtype)
+        if llr.size % self.N_cw:
+            raise NRLDPCError("llr should hold a whole number of codewords of length %d" % self.N_cw)
+        B = llr.size // self.N_cw
+        hard = np.empty((B, self.K), np.uint8)
+        iters = np.empty(B, np.int32) if want_iters else None
+        check(self._lib.nrldpc_pool_decode(self._p, _ptr(llr), B, _ptr(hard), _ptr(iters)))
+        return (hard, iters) if want_iters else hard
+
+    def last_split(self):
+        """Codewords each shard decoded in the last call (uneven under early termination: faster shards pull more)."""
+        out = (C.c_int32 * len(self.device_ids))()
+        check(self._lib.nrldpc_pool_last_split(self._p, out))
+        return list(out)
+
+    def close(self):
+        if getattr(self, "_p", None) and self._p.value:
+            self._lib.nrldpc_pool_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def decode_multi_dev(codecs, d_llr, batch, d_hard, d_iters=None, stream=0):
     """One launch per base graph and LLR type for a mix of configurations (nrldpc_decode_multi_dev):
     codecs[i] decodes batch[i] codewords at device address d_llr[i] into d_hard[i] (and d_iters[i])."""
@@ -237,6 +297,17 @@ def crc_check_dev(p, d_c_hat, n_tb, d_b_hat, d_ok, d_cb_pass=None, stream=0):
     t = p if isinstance(p, TbParams) else tb_params(p)
     check(load().nrldpc_crc_check_dev(C.byref(t), _ptr(d_c_hat), int(n_tb), _ptr(d_b_hat), _ptr(d_ok),
                                       _ptr(d_cb_pass), C.c_void_p(stream)))
+
+
+def crc_check_harq_dev(p, d_c_hat, n_tb, d_b_hat, d_ok, d_cb_pass, cbgti_flags=None, keep_b_hat=True, stream=0):
+    """nrldpc_crc_check_harq_dev: the CRC stage with the reference's HARQ / CBGTI state (NRLDPCDecoder.m:283-316,337).
+    d_b_hat and d_cb_pass are in/out device buffers owned by the caller; cbgti_flags is a host sequence of C flags."""
+    t = p if isinstance(p, TbParams) else tb_params(p)
+    flags = None
+    if cbgti_flags is not None:
+        flags = (C.c_uint8 * t.C)(*[1 if f else 0 for f in cbgti_flags])
+    check(load().nrldpc_crc_check_harq_dev(C.byref(t), _ptr(d_c_hat), int(n_tb), _ptr(d_b_hat), _ptr(d_ok),
+                                           _ptr(d_cb_pass), flags, int(bool(keep_b_hat)), C.c_void_p(stream)))
 
 
 def crc_attach_dev(p, d_a, n_tb, d_c, stream=0):

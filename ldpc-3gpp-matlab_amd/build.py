@@ -3,6 +3,7 @@
 Every translation unit is compiled to an object in parallel (the compile-time-Z decoder is instantiated
 once per (BG, Z) pair from one source with -D flags), then linked into one in-tree shared object.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -38,11 +39,26 @@ def _deps():
     return [p for p in d if os.path.exists(p)]
 
 
+def source_id():
+    """Hash of every source the library is built from (contents, not mtimes: a snapshot copied to a GPU box keeps
+    contents but not times).  Compiled into the library (nrldpc_build_id) and written next to it (<lib>.id)."""
+    h = hashlib.sha256()
+    for d in sorted(_deps()):
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
+    """The library is missing, or was built from other sources than the ones in the tree now."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    try:
+        with open(LIB + ".id") as f:
+            return f.read().strip() != source_id()
+    except OSError:
+        return True
 
 
 def build_lib(force=False, verbose=False, jobs=None):
@@ -50,9 +66,11 @@ def build_lib(force=False, verbose=False, jobs=None):
     if not force and not _stale():
         return LIB
     hipcc = _hipcc()
+    sid = source_id()
     os.makedirs(OBJDIR, exist_ok=True)
     inc = ["-I" + INCLUDE, "-I" + CSRC]
-    units = [(os.path.join(CSRC, f), os.path.join(OBJDIR, f.replace(".hip", ".o")), []) for f in SOURCES]
+    units = [(os.path.join(CSRC, f), os.path.join(OBJDIR, f.replace(".hip", ".o")),
+              ['-DNRLDPC_BUILD_ID="%s"' % sid] if f == "nrldpc_capi.hip" else []) for f in SOURCES]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d.o" % (bg, z)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64_PAIRS]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
@@ -61,7 +79,7 @@ def build_lib(force=False, verbose=False, jobs=None):
 
     def compile_one(u):
         src, obj, defs = u
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest and not src.endswith("nrldpc_capi.hip"):
             return obj
         cmd = [hipcc, *FLAGS, *inc, *defs, "-c", src, "-o", obj]
         if verbose:
@@ -77,6 +95,8 @@ def build_lib(force=False, verbose=False, jobs=None):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(LIB + ".id", "w") as f:
+        f.write(sid + "\n")
     return LIB
 
 

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -37,6 +38,30 @@ int hipfail(hipError_t e, const char* what) {
         hipError_t _e = (expr);                        \
         if (_e != hipSuccess) return hipfail(_e, #expr); \
     } while (0)
+
+// extern "C" bodies must not let C++ exceptions (std::bad_alloc from the staging vectors, std::system_error from the
+// copy threads) cross the ABI: they become return codes.
+#define NRLDPC_API_BEGIN try {
+#define NRLDPC_API_END                                                                                   \
+    }                                                                                                    \
+    catch (const std::bad_alloc&) { return fail(NRLDPC_ERR_NOMEM, "host allocation failed"); }           \
+    catch (const std::exception& ex) { return fail(NRLDPC_ERR_HIP, std::string("internal error: ") + ex.what()); } \
+    catch (...) { return fail(NRLDPC_ERR_HIP, "internal error"); }
+
+// Makes the handle's device current for the duration of a call and puts the caller's device back afterwards: a
+// caller that drives several GPUs from one thread (or whose framework tracks its own current device) is not disturbed.
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define DEVICE_SCOPE(h)                                  \
+    DeviceScope _scope((h)->cfg.device_id);              \
+    if (_scope.err != hipSuccess) return hipfail(_scope.err, "hipSetDevice")
 
 template <class T> struct DevBuf {
     T* p = nullptr;
@@ -152,7 +177,12 @@ struct nrldpc_codec {
     DevBuf<int32_t> s_iters;
     DevBuf<float> s_app;
     std::vector<float> h_narrow;
-    DevBuf<char> multi_tab; // argument blocks + workgroup prefix tables of nrldpc_decode_multi_dev
+    // argument blocks + workgroup prefix tables of nrldpc_decode_multi_dev: a ring of slots (pinned host copy, device
+    // copy, completion event), so that calls in flight on different streams never share a table
+    struct MultiSlot { PinBuf pin; DevBuf<char> dev; hipEvent_t done = nullptr; bool used = false; };
+    static constexpr int kMultiSlots = 4;
+    MultiSlot multi[kMultiSlots];
+    int multi_next = 0;
     // pipelined host path (large batches): two pinned slots, two streams, copy threads
     PinBuf pin_in[2], pin_out[2], pin_it[2];
     hipStream_t xs[2] = {nullptr, nullptr};
@@ -285,7 +315,11 @@ const char* nrldpc_strerror(int code) {
     }
 }
 const char* nrldpc_last_error(void) { return g_err.c_str(); }
-const char* nrldpc_version(void) { return "nrldpc-hip 0.1 (gfx950)"; }
+const char* nrldpc_version(void) { return "nrldpc-hip 0.2 (gfx950)"; }
+#ifndef NRLDPC_BUILD_ID
+#define NRLDPC_BUILD_ID "unknown"
+#endif
+const char* nrldpc_build_id(void) { return NRLDPC_BUILD_ID; }
 
 int nrldpc_default_rule(int32_t bg, int32_t n_layers, float* alpha, float* beta) {
     if (bg != 1 && bg != 2) return fail(NRLDPC_ERR_UNSUPPORTED, "BG must be 1 or 2");
@@ -300,6 +334,7 @@ int nrldpc_default_rule(int32_t bg, int32_t n_layers, float* alpha, float* beta)
 }
 
 int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
+    NRLDPC_API_BEGIN
     if (!cfg || !out) return fail(NRLDPC_ERR_ARG, "null cfg/out");
     *out = nullptr;
     if (cfg->bg != 1 && cfg->bg != 2) return fail(NRLDPC_ERR_UNSUPPORTED, "BG must be 1 or 2");
@@ -348,7 +383,8 @@ int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
         hipError_t _e = (expr);                                           \
         if (_e != hipSuccess) { int rc = hipfail(_e, #expr); nrldpc_destroy(h); return rc; } \
     } while (0)
-    CREATE_TRY(hipSetDevice(cfg->device_id));
+    DeviceScope scope(cfg->device_id); // the caller's current device is restored on return
+    CREATE_TRY(scope.err);
     const nrldpc::Schedule& s = h->sched;
     CREATE_TRY(h->d_rot.reserve(s.rot.size()));
     CREATE_TRY(hipMemcpy(h->d_rot.p, s.rot.data(), s.rot.size() * 4, hipMemcpyHostToDevice));
@@ -364,15 +400,16 @@ int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
 #undef CREATE_TRY
     *out = h;
     return NRLDPC_OK;
+    NRLDPC_API_END
 }
 
 void nrldpc_destroy(nrldpc_handle h) {
     if (!h) return;
-    (void)hipSetDevice(h->cfg.device_id);
+    DeviceScope scope(h->cfg.device_id);
     h->d_rot.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
     h->s_llr.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
-    h->multi_tab.release();
+    for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int i = 0; i < 2; ++i) {
@@ -415,12 +452,13 @@ int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t
     if (batch == 0) return NRLDPC_OK;
     if (!d_llr || !d_hard) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
     if (h->cfg.llr_dtype == NRLDPC_LLR_F64) return fail(NRLDPC_ERR_ARG, "f64 LLRs are accepted by the host entry point only");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    DEVICE_SCOPE(h);
     return decode_launch(h, d_llr, batch, d_hard, d_iters_out, d_app_out, static_cast<hipStream_t>(stream));
 }
 
 int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* const* d_llr, const int32_t* batch,
                             uint8_t* const* d_hard, int32_t* const* d_iters, void* stream) {
+    NRLDPC_API_BEGIN
     if (n < 0) return fail(NRLDPC_ERR_ARG, "negative configuration count");
     if (n == 0) return NRLDPC_OK;
     if (!hs || !d_llr || !batch || !d_hard) return fail(NRLDPC_ERR_ARG, "null array");
@@ -432,15 +470,24 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
         if (hs[i]->cfg.device_id != hs[0]->cfg.device_id) return fail(NRLDPC_ERR_ARG, "all handles of one call must live on one device");
     }
     nrldpc_codec* own = hs[0]; // its scratch holds the tables
-    HIP_TRY(hipSetDevice(own->cfg.device_id));
+    DEVICE_SCOPE(own);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // one group per (base graph, LLR type): argument blocks, then the workgroup prefix table
+    // A configuration whose (BG, Z) has a compile-time-Z kernel and whose batch fills the chip at least once goes to
+    // that kernel in a launch of its own (0.55-0.7x the time per codeword); everything else shares ONE launch of the
+    // run-time-Z kernel per (base graph, LLR type): argument blocks, then the workgroup prefix table.
+    static const long env_rows = getenv("NRLDPC_MULTI_Z64_MIN_ROWS") ? atol(getenv("NRLDPC_MULTI_Z64_MIN_ROWS")) : 512L * 384L;
     struct Group { std::vector<nrldpc::DecArgs> args; std::vector<int32_t> start; size_t lds = 0; int grid = 0; };
     Group g[2][2];
     for (int i = 0; i < n; ++i) {
         if (batch[i] == 0) continue;
-        const nrldpc_codec* h = hs[i];
+        nrldpc_codec* h = hs[i];
         const nrldpc::Schedule& s = h->sched;
+        if ((long)batch[i] * s.Z >= env_rows && nrldpc::has_z64_kernel(s.g.bg, s.Z)) {
+            const nrldpc::DecArgs a = make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr);
+            hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, st);
+            if (e != hipSuccess) return hipfail(e, "decode kernel launch");
+            continue;
+        }
         Group& q = g[s.g.bg - 1][h->cfg.llr_dtype == NRLDPC_LLR_F16 ? 1 : 0];
         q.args.push_back(make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr));
         q.start.push_back(q.grid);
@@ -463,26 +510,38 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
                         reinterpret_cast<const char*>(q.start.data() + q.start.size()));
         }
     if (host.empty()) return NRLDPC_OK;
-    HIP_TRY(own->multi_tab.reserve(host.size()));
-    HIP_TRY(hipMemcpyAsync(own->multi_tab.p, host.data(), host.size(), hipMemcpyHostToDevice, st)); // pageable: staged before return
-    for (int b = 0; b < 2; ++b)
-        for (int d = 0; d < 2; ++d) {
+    // table slot: reused only after the launches that read it have completed (calls on different streams may overlap)
+    nrldpc_codec::MultiSlot& m = own->multi[own->multi_next];
+    own->multi_next = (own->multi_next + 1) % nrldpc_codec::kMultiSlots;
+    if (!m.done) HIP_TRY(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
+    if (m.used) HIP_TRY(hipEventSynchronize(m.done));
+    HIP_TRY(m.pin.reserve(host.size()));
+    HIP_TRY(m.dev.reserve(host.size()));
+    memcpy(m.pin.p, host.data(), host.size());
+    HIP_TRY(hipMemcpyAsync(m.dev.p, m.pin.p, host.size(), hipMemcpyHostToDevice, st));
+    int rc = NRLDPC_OK;
+    for (int b = 0; b < 2 && rc == NRLDPC_OK; ++b)
+        for (int d = 0; d < 2 && rc == NRLDPC_OK; ++d) {
             const Group& q = g[b][d];
             if (q.args.empty()) continue;
             hipError_t e = nrldpc::launch_decode_multi(
-                b + 1, d ? NRLDPC_K_F16 : NRLDPC_K_F32, reinterpret_cast<const nrldpc::DecArgs*>(own->multi_tab.p + off[b][d][0]),
-                reinterpret_cast<const int32_t*>(own->multi_tab.p + off[b][d][1]), (int)q.args.size(), q.grid, q.lds, st);
-            if (e != hipSuccess) return hipfail(e, "multi-configuration decode launch");
+                b + 1, d ? NRLDPC_K_F16 : NRLDPC_K_F32, reinterpret_cast<const nrldpc::DecArgs*>(m.dev.p + off[b][d][0]),
+                reinterpret_cast<const int32_t*>(m.dev.p + off[b][d][1]), (int)q.args.size(), q.grid, q.lds, st);
+            if (e != hipSuccess) rc = hipfail(e, "multi-configuration decode launch");
         }
-    return NRLDPC_OK;
+    (void)hipEventRecord(m.done, st); // also on a failed launch: the copy above is in flight
+    m.used = true;
+    return rc;
+    NRLDPC_API_END
 }
 
 int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out) {
+    NRLDPC_API_BEGIN
     if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
     if (batch == 0) return NRLDPC_OK;
     if (!llr || !hard) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    DEVICE_SCOPE(h);
     const nrldpc::Schedule& s = h->sched;
     const size_t ncw = (size_t)s.g.ncols * s.Z, K = (size_t)s.g.kb * s.Z;
     const size_t cap = (h->cfg.max_batch > batch) ? (size_t)h->cfg.max_batch : (size_t)batch;
@@ -517,6 +576,11 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
             if (!h->xdone[i]) HIP_TRY(hipEventCreateWithFlags(&h->xdone[i], hipEventDisableTiming));
         }
         const int nchunks = (batch + chunk - 1) / chunk;
+        // an early error return must not leave copies or kernels of this call in flight on the two streams
+        struct Quiesce {
+            hipStream_t* xs; bool armed = true;
+            ~Quiesce() { if (armed) for (int i = 0; i < 2; ++i) if (xs[i]) (void)hipStreamSynchronize(xs[i]); }
+        } quiesce{h->xs};
         auto drain = [&](int k) -> int { // results of chunk k: pinned slot -> caller arrays
             const int sl = k & 1, c0 = k * chunk, n = std::min(chunk, batch - c0);
             HIP_TRY(hipEventSynchronize(h->xdone[sl]));
@@ -539,6 +603,7 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
             HIP_TRY(hipEventRecord(h->xdone[sl], h->xs[sl]));
         }
         for (int k = std::max(0, nchunks - 2); k < nchunks; ++k) { int rc = drain(k); if (rc) return rc; }
+        quiesce.armed = false; // every chunk was drained behind its event
         return NRLDPC_OK;
     }
 
@@ -559,6 +624,128 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     if (app_out) HIP_TRY(hipMemcpyAsync(app_out, h->s_app.p, (size_t)batch * ncw * 4, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     return NRLDPC_OK;
+    NRLDPC_API_END
+}
+
+} // extern "C"
+
+// ---- multi-GPU pool: N handles, N host threads, a queue of chunks ------------------------------------------------
+struct nrldpc_pool {
+    std::vector<nrldpc_handle> hs;
+    std::vector<std::thread> th;
+    std::vector<int32_t> split;
+    int chunks_per_device = 2;
+    size_t ncw = 0, K = 0, eb = 0;
+    // one job at a time (the pool, like a handle, is driven by one caller thread)
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    unsigned gen = 0;
+    bool stop = false;
+    const char* llr = nullptr; uint8_t* hard = nullptr; int32_t* iters = nullptr;
+    int batch = 0, chunk = 0, nchunks = 0, next = 0, running = 0, rc = NRLDPC_OK;
+    std::string err;
+
+    void worker(int i) {
+        unsigned seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            for (;;) {
+                int k;
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    if (next >= nchunks || rc != NRLDPC_OK) break;
+                    k = next++;
+                }
+                const int c0 = k * chunk, n = std::min(chunk, batch - c0);
+                const int r = nrldpc_decode(hs[i], llr + (size_t)c0 * ncw * eb, n, hard + (size_t)c0 * K,
+                                            iters ? iters + c0 : nullptr, nullptr);
+                std::lock_guard<std::mutex> lk(m);
+                if (r != NRLDPC_OK && rc == NRLDPC_OK) { rc = r; err = nrldpc_last_error(); }
+                split[i] += n;
+            }
+            std::lock_guard<std::mutex> lk(m);
+            if (--running == 0) cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t n_devices, int32_t chunks_per_device,
+                       nrldpc_pool_handle* out) {
+    NRLDPC_API_BEGIN
+    if (!cfg || !device_ids || !out) return fail(NRLDPC_ERR_ARG, "null cfg/device_ids/out");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64) return fail(NRLDPC_ERR_ARG, "n_devices must be in 1..64");
+    if (chunks_per_device < 1 || chunks_per_device > 64) return fail(NRLDPC_ERR_ARG, "chunks_per_device must be in 1..64");
+    nrldpc_pool* p = new nrldpc_pool();
+    p->chunks_per_device = chunks_per_device;
+    for (int i = 0; i < n_devices; ++i) {
+        nrldpc_cfg c = *cfg;
+        c.device_id = device_ids[i];
+        nrldpc_handle h = nullptr;
+        const int rc = nrldpc_create(&c, &h);
+        if (rc != NRLDPC_OK) {
+            for (auto q : p->hs) nrldpc_destroy(q);
+            delete p;
+            return rc; // text of nrldpc_create's failure is already in place
+        }
+        p->hs.push_back(h);
+    }
+    const nrldpc::Schedule& s = p->hs[0]->sched;
+    p->ncw = (size_t)s.g.ncols * s.Z; p->K = (size_t)s.g.kb * s.Z;
+    p->eb = cfg->llr_dtype == NRLDPC_LLR_F64 ? 8 : cfg->llr_dtype == NRLDPC_LLR_F16 ? 2 : 4; // in the caller's array
+    p->split.assign(n_devices, 0);
+    for (int i = 0; i < n_devices; ++i) p->th.emplace_back([p, i] { p->worker(i); });
+    *out = p;
+    return NRLDPC_OK;
+    NRLDPC_API_END
+}
+
+int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out) {
+    NRLDPC_API_BEGIN
+    if (!p) return fail(NRLDPC_ERR_ARG, "null pool");
+    if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (batch == 0) return NRLDPC_OK;
+    if (!llr || !hard) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
+    std::unique_lock<std::mutex> lk(p->m);
+    const int want = (int)p->hs.size() * p->chunks_per_device;
+    p->chunk = std::max(1, (batch + want - 1) / want);
+    p->nchunks = (batch + p->chunk - 1) / p->chunk;
+    p->llr = static_cast<const char*>(llr); p->hard = hard; p->iters = iters_out; p->batch = batch;
+    p->next = 0; p->rc = NRLDPC_OK; p->err.clear();
+    std::fill(p->split.begin(), p->split.end(), 0);
+    p->running = (int)p->th.size();
+    ++p->gen;
+    p->cv.notify_all();
+    p->cv_done.wait(lk, [&] { return p->running == 0; });
+    if (p->rc != NRLDPC_OK) return fail(p->rc, p->err);
+    return NRLDPC_OK;
+    NRLDPC_API_END
+}
+
+int nrldpc_pool_last_split(nrldpc_pool_handle p, int32_t* counts) {
+    if (!p || !counts) return fail(NRLDPC_ERR_ARG, "null pool/counts");
+    std::lock_guard<std::mutex> lk(p->m);
+    for (size_t i = 0; i < p->split.size(); ++i) counts[i] = p->split[i];
+    return NRLDPC_OK;
+}
+
+void nrldpc_pool_destroy(nrldpc_pool_handle p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        p->stop = true;
+    }
+    p->cv.notify_all();
+    for (auto& t : p->th) t.join();
+    for (auto h : p->hs) nrldpc_destroy(h);
+    delete p;
 }
 
 static uint32_t crc_poly_for(int len, bool code_block) {
@@ -631,13 +818,14 @@ int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, i
     return NRLDPC_OK;
 }
 
-int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat,
-                         int32_t* d_ok, int32_t* d_cb_pass, void* stream) {
+static int crc_check_common(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat, int32_t* d_ok,
+                            int32_t* d_cb_pass, const uint8_t* cbgti_flags, int keep_b_hat, int sticky, void* stream) {
     int rc = check_tb_params(p);
     if (rc) return rc;
     if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
     if (n_tb == 0) return NRLDPC_OK;
     if (!d_c_hat || !d_b_hat || !d_ok) return fail(NRLDPC_ERR_ARG, "null pointer");
+    if (sticky && !d_cb_pass) return fail(NRLDPC_ERR_ARG, "the sticky code-block flags (d_cb_pass) are required");
     if ((p->tb_crc_len != 16 && p->tb_crc_len != 24) || (p->cb_crc_len != 0 && p->cb_crc_len != 24))
         return fail(NRLDPC_ERR_UNSUPPORTED, "CRC lengths must be 16/24 (TB) and 0/24 (CB)");
     if (p->B != p->A + p->tb_crc_len || p->C * (p->K_prime - p->cb_crc_len) != p->B)
@@ -645,12 +833,25 @@ int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int3
     nrldpc::CrcArgs a;
     a.c_hat = d_c_hat; a.b_hat = d_b_hat; a.ok = d_ok; a.cb_pass = d_cb_pass;
     a.n_tb = n_tb; a.C = p->C; a.K = p->K; a.Kp = p->K_prime; a.Lcb = p->cb_crc_len; a.A = p->A; a.B = p->B;
+    a.keep_b_hat = keep_b_hat ? 1 : 0; a.sticky = sticky ? 1 : 0;
+    for (int r = 0; r < NRLDPC_MAX_C; ++r) a.cbgti[r] = (cbgti_flags && r < p->C) ? (cbgti_flags[r] ? 1 : 0) : 1;
     const int pay = p->K_prime - p->cb_crc_len;
     make_crc_plan(&a.tb, crc_poly_for(p->tb_crc_len, false), p->tb_crc_len, pay, pay, pay);
     make_crc_plan(&a.cb, crc_poly_for(24, true), 24, p->K_prime, 0, 0);
     hipError_t e = nrldpc::launch_crc_check(a, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hipfail(e, "CRC kernel launch");
     return NRLDPC_OK;
+}
+
+int nrldpc_crc_check_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat,
+                         int32_t* d_ok, int32_t* d_cb_pass, void* stream) {
+    return crc_check_common(p, d_c_hat, n_tb, d_b_hat, d_ok, d_cb_pass, nullptr, 0, 0, stream);
+}
+
+int nrldpc_crc_check_harq_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat,
+                              int32_t* d_ok, int32_t* d_cb_pass, const uint8_t* cbgti_flags, int32_t keep_b_hat,
+                              void* stream) {
+    return crc_check_common(p, d_c_hat, n_tb, d_b_hat, d_ok, d_cb_pass, cbgti_flags, keep_b_hat, 1, stream);
 }
 
 int nrldpc_crc_attach_dev(const nrldpc_tb_params* p, const uint8_t* d_a, int32_t n_tb, uint8_t* d_c, void* stream) {
@@ -700,7 +901,7 @@ int nrldpc_encode_dev(nrldpc_handle h, const uint8_t* d_info, int32_t batch, uin
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
     if (batch == 0) return NRLDPC_OK;
     if (!d_info || !d_cw) return fail(NRLDPC_ERR_ARG, "null info/cw pointer");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    DEVICE_SCOPE(h);
     return encode_launch(h, d_info, batch, d_cw, static_cast<hipStream_t>(stream));
 }
 
@@ -709,7 +910,7 @@ int nrldpc_encode(nrldpc_handle h, const uint8_t* info, int32_t batch, uint8_t* 
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
     if (batch == 0) return NRLDPC_OK;
     if (!info || !cw) return fail(NRLDPC_ERR_ARG, "null info/cw pointer");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    DEVICE_SCOPE(h);
     const nrldpc::Schedule& s = h->sched;
     const size_t ncw = (size_t)s.g.ncols * s.Z, K = (size_t)s.g.kb * s.Z;
     HIP_TRY(h->s_bits.reserve((size_t)batch * K));

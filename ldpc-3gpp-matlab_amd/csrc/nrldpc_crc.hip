@@ -79,20 +79,39 @@ __global__ __launch_bounds__(256) void nrldpc_crc_check_kernel(const CrcArgs a) 
         wave_lds_sync();
         int fail = 0;
         if (a.C > 1) fail = wave_crc(row, a.Kp, a.cb) != 0;  // NRLDPCDecoder.m:298-301
-        const uint32_t p = wave_crc(row, pay, a.tb);
-        if (lane == 0) { cb_fail[r] = fail; part[r] = p; }
-        store_row(b_hat + (size_t)r * pay, row, pay);       // :303-309 payload copy
+        const bool take = !fail && a.cbgti[r] != 0;          // :304: CRC holds and the block was (re)transmitted
+        uint32_t p;
+        if (take) {
+            p = wave_crc(row, pay, a.tb);
+            store_row(b_hat + (size_t)r * pay, row, pay);    // :303-309 payload copy
+        } else if (a.keep_b_hat) {                           // :286-287: the segment keeps what an earlier step stored
+            wave_lds_sync();
+            row = stage_row(base, b_hat + (size_t)r * pay, pay);
+            wave_lds_sync();
+            p = wave_crc(row, pay, a.tb);
+        } else {                                             // :289: b_hat = zeros(B,1)
+            p = 0;
+            uint8_t* z = b_hat + (size_t)r * pay;
+            for (int i = lane; i < pay; i += 64) z[i] = 0;
+        }
+        if (lane == 0) { cb_fail[r] = take ? 0 : 1; part[r] = p; }
     }
     __syncthreads();
     if (wave == 0) {
         uint32_t reg = 0;                                    // :336 over b_hat = segment 0 || ... || segment C-1
         for (int r = 0; r < a.C; ++r) reg = gf2_apply(a.tb.horner, reg) ^ part[r];
-        int any_cb = 0;
-        for (int r = lane; r < a.C; r += 64) any_cb |= cb_fail[r];
+        int any_cb = 0;                                      // :337 any(~code_block_CRC_passed), flags sticky (:305,315)
+        for (int r = lane; r < a.C; r += 64) {
+            int pass = cb_fail[r] ? 0 : 1;
+            if (a.cb_pass) {
+                int32_t* f = a.cb_pass + (size_t)tb * a.C + r;
+                if (a.sticky) pass |= (*f != 0);
+                *f = pass;
+            }
+            any_cb |= !pass;
+        }
         any_cb = __any(any_cb);
         if (lane == 0) a.ok[tb] = (reg != 0 || any_cb) ? 0 : 1; // :337-339
-        if (a.cb_pass)
-            for (int r = lane; r < a.C; r += 64) a.cb_pass[(size_t)tb * a.C + r] = cb_fail[r] ? 0 : 1;
     }
 }
 

@@ -314,8 +314,21 @@ template <int BG, int DT> static hipError_t launch_t(const DecArgs& a, int grid,
     return hipGetLastError();
 }
 
+static bool force_generic_env() {
+    static const bool f = getenv("NRLDPC_FORCE_GENERIC") != nullptr; // A/B of the two kernels (tools/bench_all_z.py)
+    return f;
+}
+
+bool has_z64_kernel(int bg, int Z) {
+    if (force_generic_env()) return false;
+#define NRLDPC_Z64_CASE(b, z) if (bg == b && Z == z) return true;
+    NRLDPC_Z64_LIST(NRLDPC_Z64_CASE)
+#undef NRLDPC_Z64_CASE
+    return false;
+}
+
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
-    static const bool force_generic = getenv("NRLDPC_FORCE_GENERIC") != nullptr; // A/B of the two kernels (tools/bench_all_z.py)
+    const bool force_generic = force_generic_env();
 #define NRLDPC_Z64_CASE(b, z) if (!force_generic && bg == b && a.Z == z) return launch_decode_z64_##b##_##z(a, stream);
     NRLDPC_Z64_LIST(NRLDPC_Z64_CASE)
 #undef NRLDPC_Z64_CASE

@@ -62,10 +62,21 @@ template <int BG, int ZC> constexpr int z64_ncwg() {
     return n == 8 ? 1 : n == 6 ? 2 : n == 5 ? 1 : n == 4 ? 3 : n == 3 ? 4 : n == 2 ? 2 : 4;
 }
 
-template <int BG, int ZC, int NCWG> constexpr int z64_wpe() {
+// Pruned layer counts (NRLDPC_Z64_NL_LIST) carry less message state.  Measured on MI355X (tools/exp_z64.sh with a
+// layer count): BG2 keeps its shape (one-codeword workgroups lose 10-20 %); BG1 at 5 rows (R = 8/9) gains 13-15 % as
+// one-codeword workgroups, three per CU (LDS-bound), at a register budget of 6 waves per SIMD.
+template <int BG, int ZC, int NL> constexpr int z64_ncwg_nl() {
+#ifdef NRLDPC_Z64_NCWG
+    return NRLDPC_Z64_NCWG;
+#endif
+    return (BG == 1 && z64_nwv(ZC) == 6 && NL <= 6) ? 1 : z64_ncwg<BG, ZC>();
+}
+
+template <int BG, int ZC, int NCWG, int NL = BGT<BG>::ROWS> constexpr int z64_wpe() {
 #ifdef NRLDPC_Z64_WPE
     return NRLDPC_Z64_WPE;
 #endif
+    if (BG == 1 && z64_nwv(ZC) == 6 && NL <= 6) return 6;
     return BG == 2 ? 6 : (z64_nwv(ZC) == 8 || z64_nwv(ZC) == 5 || z64_nwv(ZC) == 4 || z64_nwv(ZC) == 3) ? 4 : 3;
 }
 
@@ -447,7 +458,7 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
 // NL   : the compile-time layer count of a FULL build: all rows, or one of the pruned counts of NRLDPC_Z64_NL_LIST
 //        (the rate-matching points BASELINE.json names), each with its own barrier-group table and prefetch plan.
 template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false, int NL = BGT<BG>::ROWS>
-__global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG>())) void nrldpc_decode_z64_kernel(const DecArgs a) {
+__global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>())) void nrldpc_decode_z64_kernel(const DecArgs a) {
     static_assert(!PLAIN || FULL, "PLAIN implies FULL");
     static_assert(!ETP || (FULL && !PLAIN), "ETP implies FULL and excludes PLAIN");
     static_assert(FULL || NL == BGT<BG>::ROWS, "a run-time layer count uses the all-rows tables");

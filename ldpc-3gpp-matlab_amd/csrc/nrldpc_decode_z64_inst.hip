@@ -18,7 +18,7 @@ namespace nrldpc {
 #define NRLDPC_CAT4_(a, b, c, d) a##b##_##c##_nl##d
 #define NRLDPC_CAT4(a, b, c, d) NRLDPC_CAT4_(a, b, c, d)
 hipError_t NRLDPC_CAT4(launch_decode_z64_, NRLDPC_Z64_BG, NRLDPC_Z64_Z, NRLDPC_Z64_NL)(const DecArgs& a, hipStream_t stream) {
-    return launch_z64_pruned<NRLDPC_Z64_BG, NRLDPC_Z64_Z, z64_ncwg<NRLDPC_Z64_BG, NRLDPC_Z64_Z>(), NRLDPC_Z64_NL>(a, stream);
+    return launch_z64_pruned<NRLDPC_Z64_BG, NRLDPC_Z64_Z, z64_ncwg_nl<NRLDPC_Z64_BG, NRLDPC_Z64_Z, NRLDPC_Z64_NL>(), NRLDPC_Z64_NL>(a, stream);
 }
 #else
 hipError_t NRLDPC_CAT(launch_decode_z64_, NRLDPC_Z64_BG, NRLDPC_Z64_Z)(const DecArgs& a, hipStream_t stream) {

@@ -35,6 +35,7 @@ struct DecArgs {
 };
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream);
+bool has_z64_kernel(int bg, int Z); // a compile-time-Z specialisation serves this (BG, Z)
 // many (Z) configurations of one base graph in one launch of the run-time-Z kernel: d_tab[nb] argument blocks,
 // d_start[nb+1] first workgroup of each configuration (d_start[nb] = grid)
 hipError_t launch_decode_multi(int bg, int llr_kind, const DecArgs* d_tab, const int32_t* d_start, int nb, int grid,
@@ -100,6 +101,11 @@ struct CrcArgs {
     int32_t* ok;              // [n_tb]
     int32_t* cb_pass;         // [n_tb][C] or null
     int32_t n_tb, C, K, Kp, Lcb, A, B;
+    // reference state machine (NRLDPCDecoder.m:286-314,337): a code block's payload is written (and its pass flag
+    // set) only when its CRC holds AND its CBGTI flag is 1; otherwise b_hat keeps its content (keep_b_hat, I_HARQ != 0)
+    // or is zero (:290); pass flags are sticky across calls when `sticky` (they are in/out then)
+    int32_t keep_b_hat, sticky;
+    uint8_t cbgti[NRLDPC_MAX_C]; // CBGTI_flags (NRLDPC.m:471-477), 1 = (re)transmitted
     CrcPlan cb, tb;
 };
 hipError_t launch_crc_check(const CrcArgs& a, hipStream_t stream);

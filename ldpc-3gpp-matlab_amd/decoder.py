@@ -118,6 +118,11 @@ class NRLDPCDecoder(NRLDPC):
         else:
             self.validate()
             if g_tilde.shape[0] != self._nb:
+                if (self.code_block_CRC_passed is not None and self.code_block_CRC_passed.any()) or \
+                        (self.I_HARQ != 0 and self.d_tilde_buffer is not None and self.d_tilde_buffer.any()):
+                    # the reference never drops HARQ / CRC state without an explicit reset()
+                    raise NRLDPCError("batch size changed from %d to %d transport blocks with decoder state pending; "
+                                      "call reset() first." % (self._nb, g_tilde.shape[0]))
                 self._nb = g_tilde.shape[0]
                 self.reset()
         d_tilde = self.rate_recover(g_tilde)

@@ -6,13 +6,15 @@ with no host loop and no PCIe traffic in between.  torch is used for device memo
 """
 import numpy as np
 
-from ._capi import LLR_F16, LLR_F32, Codec, NRLDPCError, crc_check_dev, rate_recover_dev, tb_params
+from ._capi import LLR_F16, LLR_F32, Codec, NRLDPCError, crc_check_harq_dev, rate_recover_dev, tb_params
 from .nrldpc import NRLDPC
 
 
 class DeviceDecodeChain:
     """Batched NRLDPCDecoder.step on device tensors.  `params` is an NRLDPC parameter object (or any
-    NRLDPCDecoder); HARQ soft buffers live in HBM when I_HARQ is set."""
+    NRLDPCDecoder).  The DiscreteState of the reference (NRLDPCDecoder.m:64-95) lives in HBM, one row per transport
+    block of the batch: d_tilde_buffer (`harq`, only when I_HARQ), b_hat_buffer (`b_hat`) and the sticky
+    code_block_CRC_passed flags (`cb_pass`); reset() clears them (:343-356).  CBGTI of `params` is honoured (:304)."""
 
     def __init__(self, params: NRLDPC, iterations=50, I_HARQ=0, alpha=None, llr_scale=0, prune_layers=True,
                  llr_dtype=np.float16, device_id=0, beta=0.0):
@@ -27,12 +29,11 @@ class DeviceDecodeChain:
         self.device_id = device_id
         self._codec, self._codec_layers = None, None
         self._layers_seen = 4
-        self.harq = None
+        self.harq = self.b_hat = self.cb_pass = None
 
     def reset(self):
-        """reset(hDec): clears the incremental-redundancy buffer (NRLDPCDecoder.m:343-356)."""
-        if self.harq is not None:
-            self.harq.zero_()
+        """reset(hDec): clears d_tilde_buffer, b_hat_buffer and code_block_CRC_passed (NRLDPCDecoder.m:343-356)."""
+        self.harq = self.b_hat = self.cb_pass = None  # re-allocated zeroed (for any batch size) by the next step
         self._layers_seen = 4
 
     def close(self):
@@ -54,13 +55,26 @@ class DeviceDecodeChain:
         torch, p = self.torch, self.p
         if g_tilde.dim() != 2 or g_tilde.shape[1] != p.G or g_tilde.dtype != torch.float32 or not g_tilde.is_cuda:
             raise NRLDPCError("g_tilde should be a float32 device tensor of shape [n_tb][G].")
-        g_tilde = g_tilde.contiguous()
+        if g_tilde.device != self.dev:
+            raise NRLDPCError("g_tilde lives on %s, this chain on %s." % (g_tilde.device, self.dev))
+        with torch.cuda.device(self.dev):  # the stateless stage kernels launch on the current HIP device
+            return self._step(g_tilde.contiguous())
+
+    def _step(self, g_tilde):
+        torch, p = self.torch, self.p
         n_tb, C_ = g_tilde.shape[0], p.C
         t = tb_params(p)
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
         ncwz = 2 * p.Z_c + p.N
-        if self.I_HARQ and (self.harq is None or self.harq.shape[0] != n_tb):
-            self.harq = torch.zeros((n_tb, C_, p.N_cb), dtype=torch.float32, device=self.dev)
+        if self.cb_pass is not None and self.cb_pass.shape[0] != n_tb:
+            # the reference never drops HARQ / CRC state without an explicit reset(): a different batch size is an error
+            raise NRLDPCError("batch size changed from %d to %d transport blocks with decoder state pending; call "
+                              "reset() first." % (self.cb_pass.shape[0], n_tb))
+        if self.cb_pass is None:
+            self.cb_pass = torch.zeros((n_tb, C_), dtype=torch.int32, device=self.dev)
+            self.b_hat = torch.zeros((n_tb, p.B), dtype=torch.uint8, device=self.dev)
+            if self.I_HARQ:
+                self.harq = torch.zeros((n_tb, C_, p.N_cb), dtype=torch.float32, device=self.dev)
         tdt = torch.float16 if self.llr_dtype == np.float16 else torch.float32
         cw_llr = torch.empty((n_tb * C_, ncwz), dtype=tdt, device=self.dev)
         rate_recover_dev(t, g_tilde.data_ptr(), n_tb, self.harq.data_ptr() if self.I_HARQ else None,
@@ -75,10 +89,10 @@ class DeviceDecodeChain:
         c_hat = torch.empty((n_tb * C_, p.K), dtype=torch.uint8, device=self.dev)
         iters = torch.empty(n_tb * C_, dtype=torch.int32, device=self.dev)
         codec.decode_dev(cw_llr.data_ptr(), n_tb * C_, c_hat.data_ptr(), iters.data_ptr(), None, stream)
-        b_hat = torch.empty((n_tb, p.B), dtype=torch.uint8, device=self.dev)
         ok = torch.empty(n_tb, dtype=torch.int32, device=self.dev)
-        crc_check_dev(t, c_hat.data_ptr(), n_tb, b_hat.data_ptr(), ok.data_ptr(), None, stream)
-        return b_hat[:, : p.A], ok != 0, iters.view(n_tb, C_)
+        crc_check_harq_dev(t, c_hat.data_ptr(), n_tb, self.b_hat.data_ptr(), ok.data_ptr(), self.cb_pass.data_ptr(),
+                           p.CBGTI_flags, self.I_HARQ != 0, stream)
+        return self.b_hat[:, : p.A].clone(), ok != 0, iters.view(n_tb, C_)
 
 
 class DeviceEncodeChain:
@@ -105,10 +119,16 @@ class DeviceEncodeChain:
         torch, p = self.torch, self.p
         if a.dim() != 2 or a.shape[1] != p.A or a.dtype != torch.uint8 or not a.is_cuda:
             raise NRLDPCError("a should be a uint8 device tensor of shape [n_tb][A].")
-        a = a.contiguous()
+        if a.device != self.dev:
+            raise NRLDPCError("a lives on %s, this chain on %s." % (a.device, self.dev))
+        with torch.cuda.device(self.dev):
+            return self._step(a.contiguous())
+
+    def _step(self, a):
+        torch, p = self.torch, self.p
         n_tb = a.shape[0]
         t = tb_params(p)
-        s = torch.cuda.current_stream().cuda_stream
+        s = torch.cuda.current_stream(self.dev).cuda_stream
         c = torch.empty((n_tb * p.C, p.K), dtype=torch.uint8, device=self.dev)
         self._crc_attach(t, a.data_ptr(), n_tb, c.data_ptr(), s)
         cw = torch.empty((n_tb * p.C, 2 * p.Z_c + p.N), dtype=torch.uint8, device=self.dev)

@@ -3,6 +3,13 @@
 Codewords (and the C code blocks of a transport block, NRLDPCDecoder.m:257) share nothing but the
 read-only shift tables, so rank g of `world` decodes codewords [lo, hi) of the batch on its own GPU
 with its own handle.  torch.distributed is only used by callers for barriers / result gathering.
+
+Two ways to drive several GPUs of one node:
+  * one process per GPU (bench.py under torch.distributed.run): every rank builds its own Codec on its own device
+    and decodes its shard_range(); no data-path collective, RCCL carries only the barrier and the max-over-ranks time;
+  * one process, N GPUs (a MEX gateway inside one MATLAB process): _capi.CodecPool = nrldpc_pool_* in the C ABI: N
+    handles, N host threads, 2-4 chunks per GPU pulled from a queue, so that GPUs whose codewords stop early take
+    more work (BASELINE.json configs[4]).
 """
 
 

@@ -1,0 +1,133 @@
+// nrldpc_mex.cpp -- MEX gateway between the reference's System objects and libnrldpc_hip.so (include/nrldpc.h).
+//
+//   mex -I<repo>/include -L<repo>/ldpc-3gpp-matlab_amd -lnrldpc_hip nrldpc_mex.cpp
+//
+// Replaces, in robmaunder/ldpc-3gpp-matlab (see matlab/ldpc-3gpp-matlab.patch for the edits to the .m files):
+//   comm.LDPCDecoder(...) construction      NRLDPCDecoder.m:117-121   -> nrldpc_mex('create', BG, Z_c, iterations)
+//   step(obj.hLDPCDecoder, cw_tilde)        NRLDPCDecoder.m:257-266   -> nrldpc_mex('decode', id, cw_tilde)   (all C blocks)
+//   comm.LDPCEncoder(...) / step(...)       NRLDPCEncoder.m:49,158    -> nrldpc_mex('create', ...) / nrldpc_mex('encode', id, c)
+//   release of those toolbox objects                                  -> nrldpc_mex('destroy', id)
+//
+// Commands
+//   id           = nrldpc_mex('create', BG, Z_c, iterations [, n_layers [, alpha [, beta]]])
+//                  n_layers 0 / omitted = every row of H, as the reference decodes; alpha 0 / omitted = the library's
+//                  rate-dependent check-node rule (nrldpc_default_rule)
+//   [c_hat, it]  = nrldpc_mex('decode', id, cw_tilde)   cw_tilde: (N+2*Z_c) x C double, +inf fillers, 0 punctured
+//                                                       c_hat: K x C double in {0,1}; it: C x 1 int32 iterations run
+//   cw           = nrldpc_mex('encode', id, c)          c: K x C double in {0,1} (no NaN) -> (N+2*Z_c) x C double
+//   [a, b]       = nrldpc_mex('default_rule', BG, n_layers)
+//   nrldpc_mex('destroy', id)
+// Errors carry the reference's two identifiers (NRLDPCDecoder.m:149, NRLDPC.m:240-294): callers that catch
+// 'ldpc_3gpp_matlab:UnsupportedParameters' and skip (plot_BLER_vs_SNR.m:173, testbench.m:51) keep working.
+//
+// This file cannot be compiled in the build image or on the GPU box (no MATLAB, no mex.h); the same entry points are
+// driven the same way -- host pointers, doubles in, one call per batch of columns -- by tests/abi_caller/abi_caller.cpp.
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "mex.h"
+#include "nrldpc.h"
+
+namespace {
+
+std::map<uint64_t, nrldpc_handle> g_handles; // registry of live codecs; the MEX file stays locked while it is non-empty
+uint64_t g_next = 1;
+
+void at_exit() {
+    for (auto& kv : g_handles) nrldpc_destroy(kv.second);
+    g_handles.clear();
+}
+
+void check(int rc) {
+    if (rc == NRLDPC_OK) return;
+    const char* id = (rc == NRLDPC_ERR_UNSUPPORTED) ? "ldpc_3gpp_matlab:UnsupportedParameters" : "ldpc_3gpp_matlab:Error";
+    mexErrMsgIdAndTxt(id, "%s", nrldpc_last_error());
+}
+
+nrldpc_handle handle_of(const mxArray* a) {
+    const uint64_t id = (uint64_t)mxGetScalar(a);
+    auto it = g_handles.find(id);
+    if (it == g_handles.end()) mexErrMsgIdAndTxt("ldpc_3gpp_matlab:Error", "unknown or released codec handle.");
+    return it->second;
+}
+
+void need(bool ok, const char* msg) {
+    if (!ok) mexErrMsgIdAndTxt("ldpc_3gpp_matlab:Error", "%s", msg);
+}
+
+} // namespace
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    need(nrhs >= 1 && mxIsChar(prhs[0]), "first argument should be a command string.");
+    char cmd[32];
+    mxGetString(prhs[0], cmd, sizeof cmd);
+
+    if (!strcmp(cmd, "create")) {
+        need(nrhs >= 4, "create needs BG, Z_c and iterations.");
+        nrldpc_cfg cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.bg = (int32_t)mxGetScalar(prhs[1]);
+        cfg.Z = (int32_t)mxGetScalar(prhs[2]);
+        cfg.max_iter = (int32_t)mxGetScalar(prhs[3]);                  // 'MaximumIterationCount', NRLDPCDecoder.m:41,120
+        cfg.n_layers = nrhs > 4 ? (int32_t)mxGetScalar(prhs[4]) : 0;   // 0: the full H, as the reference
+        cfg.alpha = nrhs > 5 ? (float)mxGetScalar(prhs[5]) : 0.0f;     // 0: rule chosen by the library
+        cfg.beta = nrhs > 6 ? (float)mxGetScalar(prhs[6]) : 0.0f;
+        cfg.early_term = 1;                                            // 'Parity check satisfied', NRLDPCDecoder.m:120
+        cfg.llr_dtype = NRLDPC_LLR_F64;                                // MATLAB doubles straight in
+        nrldpc_handle h = nullptr;
+        check(nrldpc_create(&cfg, &h));
+        if (g_handles.empty()) { mexLock(); mexAtExit(at_exit); }
+        g_handles[g_next] = h;
+        plhs[0] = mxCreateDoubleScalar((double)g_next++);
+    } else if (!strcmp(cmd, "decode")) {
+        need(nrhs == 3 && mxIsDouble(prhs[2]) && !mxIsComplex(prhs[2]), "decode needs a handle and a real double matrix.");
+        nrldpc_handle h = handle_of(prhs[1]);
+        nrldpc_dims d;
+        check(nrldpc_get_dims(h, &d));
+        need((int)mxGetM(prhs[2]) == d.N_cw, "cw_tilde should have N+2*Z_c rows.");
+        const int C = (int)mxGetN(prhs[2]);
+        std::vector<uint8_t> hard((size_t)d.K * (size_t)(C > 0 ? C : 1));
+        mxArray* it = mxCreateNumericMatrix(C, 1, mxINT32_CLASS, mxREAL);
+        check(nrldpc_decode(h, mxGetPr(prhs[2]), C, hard.data(), (int32_t*)mxGetData(it), nullptr));
+        plhs[0] = mxCreateDoubleMatrix(d.K, C, mxREAL);                // K x C double {0,1}, what double(step(...)) gives, :265
+        double* o = mxGetPr(plhs[0]);
+        for (size_t i = 0; i < (size_t)d.K * C; ++i) o[i] = (double)hard[i];
+        if (nlhs > 1) plhs[1] = it; else mxDestroyArray(it);
+    } else if (!strcmp(cmd, "encode")) {
+        need(nrhs == 3 && mxIsDouble(prhs[2]) && !mxIsComplex(prhs[2]), "encode needs a handle and a real double matrix.");
+        nrldpc_handle h = handle_of(prhs[1]);
+        nrldpc_dims d;
+        check(nrldpc_get_dims(h, &d));
+        need((int)mxGetM(prhs[2]) == d.K, "c should have K rows.");
+        const int C = (int)mxGetN(prhs[2]);
+        const double* c = mxGetPr(prhs[2]);
+        std::vector<uint8_t> info((size_t)d.K * (size_t)(C > 0 ? C : 1)), cw((size_t)d.N_cw * (size_t)(C > 0 ? C : 1));
+        for (size_t i = 0; i < (size_t)d.K * C; ++i) {
+            need(c[i] == 0.0 || c[i] == 1.0, "c should hold bits (fillers already set to 0, NRLDPCEncoder.m:153).");
+            info[i] = (uint8_t)c[i];
+        }
+        check(nrldpc_encode(h, info.data(), C, cw.data()));            // systematic [c; w], H*cw = 0, NRLDPCEncoder.m:158
+        plhs[0] = mxCreateDoubleMatrix(d.N_cw, C, mxREAL);
+        double* o = mxGetPr(plhs[0]);
+        for (size_t i = 0; i < (size_t)d.N_cw * C; ++i) o[i] = (double)cw[i];
+    } else if (!strcmp(cmd, "default_rule")) {
+        need(nrhs >= 2, "default_rule needs BG [, n_layers].");
+        float a = 0, b = 0;
+        check(nrldpc_default_rule((int32_t)mxGetScalar(prhs[1]), nrhs > 2 ? (int32_t)mxGetScalar(prhs[2]) : 0, &a, &b));
+        plhs[0] = mxCreateDoubleScalar(a);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(b);
+    } else if (!strcmp(cmd, "destroy")) {
+        need(nrhs == 2, "destroy needs a handle.");
+        const uint64_t id = (uint64_t)mxGetScalar(prhs[1]);
+        auto it = g_handles.find(id);
+        if (it != g_handles.end()) {
+            nrldpc_destroy(it->second);
+            g_handles.erase(it);
+            if (g_handles.empty()) mexUnlock();
+        }
+    } else {
+        mexErrMsgIdAndTxt("ldpc_3gpp_matlab:Error", "unknown command '%s'.", cmd);
+    }
+}

@@ -1,0 +1,90 @@
+// abi_caller.cpp -- a plain C++ caller of include/nrldpc.h, the way a MEX gateway (matlab/nrldpc_mex.cpp) reaches the
+// library: host pointers only, MATLAB-style column-major doubles, one call per batch of code blocks, error codes.
+// No HIP headers, no Python.  Built by tests/test_abi_caller_gpu.py:
+//     g++ -O2 -std=c++17 -I include tests/abi_caller/abi_caller.cpp -L ldpc-3gpp-matlab_amd -lnrldpc_hip -o abi_caller
+// usage: abi_caller <bg> <Z> <C> <EsN0_dB> <iterations> [n_filler]
+// Prints one JSON line; exit code 0 iff every check held.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "nrldpc.h"
+
+static uint64_t g_state = 0x9E3779B97F4A7C15ull;
+static double uniform01() { // xorshift64*: the caller's own noise, nothing from the library
+    g_state ^= g_state >> 12; g_state ^= g_state << 25; g_state ^= g_state >> 27;
+    return (double)((g_state * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0;
+}
+static double gauss() { return std::sqrt(-2.0 * std::log(uniform01() + 1e-300)) * std::cos(6.283185307179586 * uniform01()); }
+
+#define CHECK(cond, what)                                                         \
+    do {                                                                          \
+        if (!(cond)) { std::fprintf(stderr, "FAILED: %s (%s)\n", what, nrldpc_last_error()); return 1; } \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 6) { std::fprintf(stderr, "usage: abi_caller bg Z C EsN0_dB iterations [n_filler]\n"); return 2; }
+    const int bg = std::atoi(argv[1]), Z = std::atoi(argv[2]), C = std::atoi(argv[3]), iters = std::atoi(argv[5]);
+    const double esn0 = std::atof(argv[4]);
+    const int n_filler = argc > 6 ? std::atoi(argv[6]) : 0;
+
+    // error convention first: an invalid lifting size is "unsupported", not a crash (get_3gpp_set_index.m:10)
+    nrldpc_cfg bad;
+    std::memset(&bad, 0, sizeof bad);
+    bad.bg = bg; bad.Z = 100; bad.max_iter = iters; bad.llr_dtype = NRLDPC_LLR_F64;
+    nrldpc_handle h = nullptr;
+    CHECK(nrldpc_create(&bad, &h) == NRLDPC_ERR_UNSUPPORTED && h == nullptr, "invalid Z is NRLDPC_ERR_UNSUPPORTED");
+    CHECK(nrldpc_create(nullptr, &h) == NRLDPC_ERR_ARG, "null cfg is NRLDPC_ERR_ARG");
+
+    nrldpc_cfg cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.bg = bg; cfg.Z = Z; cfg.max_iter = iters; cfg.early_term = 1;   // NRLDPCDecoder.m:120
+    cfg.llr_dtype = NRLDPC_LLR_F64;                                     // MATLAB doubles; alpha = 0: the library's rule
+    CHECK(nrldpc_create(&cfg, &h) == NRLDPC_OK, "nrldpc_create");
+    nrldpc_dims d;
+    CHECK(nrldpc_get_dims(h, &d) == NRLDPC_OK, "nrldpc_get_dims");
+    float ra = 0, rb = 0;
+    CHECK(nrldpc_default_rule(bg, 0, &ra, &rb) == NRLDPC_OK && ra == d.alpha && rb == d.beta, "create applied nrldpc_default_rule");
+    const size_t K = (size_t)d.K, N = (size_t)d.N_cw;
+
+    std::vector<uint8_t> info(K * C), cw(N * C), hard(K * C, 2);
+    for (size_t i = 0; i < info.size(); ++i) info[i] = uniform01() < 0.5;
+    for (int c = 0; c < C; ++c)
+        for (int k = 0; k < n_filler; ++k) info[(size_t)c * K + K - 1 - k] = 0;   // filler bits are zeros (NRLDPCEncoder.m:153)
+    CHECK(nrldpc_encode(h, info.data(), C, cw.data()) == NRLDPC_OK, "nrldpc_encode");
+    for (size_t i = 0; i < K * C; ++i) CHECK(cw[(i / K) * N + (i % K)] == info[i], "systematic codeword");
+
+    // QPSK over AWGN as plot_BLER_vs_SNR.m:105-106 with NRDemodulator's exact LLRs; first 2Z columns punctured (:262)
+    const double mu = 2.0 * std::pow(10.0, esn0 / 10.0);
+    std::vector<double> llr(N * C);
+    for (int c = 0; c < C; ++c)
+        for (size_t v = 0; v < N; ++v) {
+            double x = (1.0 - 2.0 * cw[(size_t)c * N + v]) * mu + std::sqrt(2.0 * mu) * gauss();
+            if (v < (size_t)(2 * Z)) x = 0.0;
+            if (v >= K - (size_t)n_filler && v < K) x = std::numeric_limits<double>::infinity(); // NRLDPCDecoder.m:264
+            llr[(size_t)c * N + v] = x;
+        }
+    std::vector<int32_t> it(C, -1);
+    CHECK(nrldpc_decode(h, llr.data(), C, hard.data(), it.data(), nullptr) == NRLDPC_OK, "nrldpc_decode");
+    int block_errors = 0, it_max = 0;
+    for (int c = 0; c < C; ++c) {
+        block_errors += std::memcmp(&hard[(size_t)c * K], &info[(size_t)c * K], K) != 0;
+        CHECK(it[c] >= 1 && it[c] <= iters, "iteration counts in range");
+        it_max = it[c] > it_max ? it[c] : it_max;
+    }
+    // one code block per call, the reference's own call pattern (NRLDPCDecoder.m:257-266): same bits
+    std::vector<uint8_t> one(K);
+    CHECK(nrldpc_decode(h, llr.data(), 1, one.data(), nullptr, nullptr) == NRLDPC_OK, "single-column decode");
+    CHECK(std::memcmp(one.data(), hard.data(), K) == 0, "single-column decode equals column 0 of the batch");
+    CHECK(nrldpc_decode(h, llr.data(), -1, hard.data(), nullptr, nullptr) == NRLDPC_ERR_ARG, "negative batch is NRLDPC_ERR_ARG");
+    CHECK(nrldpc_decode(h, nullptr, 1, hard.data(), nullptr, nullptr) == NRLDPC_ERR_ARG, "null llr is NRLDPC_ERR_ARG");
+    nrldpc_destroy(h);
+    std::printf("{\"bg\": %d, \"Z\": %d, \"C\": %d, \"EsN0_dB\": %.2f, \"block_errors\": %d, \"max_iterations\": %d, "
+                "\"alpha\": %.4f, \"beta\": %.4f, \"version\": \"%s\", \"build\": \"%s\"}\n",
+                bg, Z, C, esn0, block_errors, it_max, d.alpha, d.beta, nrldpc_version(), nrldpc_build_id());
+    return block_errors == 0 ? 0 : 1;
+}

@@ -65,3 +65,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "oracle/" not in src.replace("oracle/nrldpc_oracle.c", ""), f
+
+
+def test_matlab_patch_applies(tmp_path):
+    """matlab/ldpc-3gpp-matlab.patch against the reference tree (build box only: /root/reference is not on the GPU box)."""
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(ref) or not shutil.which("patch"):
+        pytest.skip("reference tree or patch(1) not available")
+    for f in ("NRLDPCDecoder.m", "NRLDPCEncoder.m"):
+        shutil.copy(os.path.join(ref, f), tmp_path / f)
+    patch = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "matlab", "ldpc-3gpp-matlab.patch")
+    subprocess.check_call(["patch", "-p1", "--binary", "-s", "-i", patch], cwd=tmp_path)
+    dec = (tmp_path / "NRLDPCDecoder.m").read_text(encoding="latin-1")
+    assert "nrldpc_mex('decode', obj.hLDPCDecoder, cw_tilde)" in dec and "comm.LDPCDecoder(" not in dec
+    assert "nrldpc_mex('encode'" in (tmp_path / "NRLDPCEncoder.m").read_text(encoding="latin-1")

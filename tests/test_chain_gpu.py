@@ -64,13 +64,17 @@ def test_crc_stage_matches_bit_serial_reference(pkg, orc, kw):
     pkg.crc_check_dev(enc, d_c.data_ptr(), n_tb, b_hat.data_ptr(), ok.data_ptr(), cbp.data_ptr())
     torch.cuda.synchronize()
     pay = Kp - L
-    exp_b = np.concatenate([c[:, r, :pay] for r in range(enc.C)], axis=1)
-    assert (b_hat.cpu().numpy() == exp_b).all()
     exp_cb = np.ones((n_tb, enc.C), np.int32)
     if enc.C > 1:
         for t in range(n_tb):
             for r in range(enc.C):
                 exp_cb[t, r] = int(orc.crc(0x1800063, 24, c[t, r, :Kp]) == 0)
+    # b_hat = zeros(B,1); a code block's payload is copied only when its CRC holds (NRLDPCDecoder.m:289,304)
+    exp_b = np.concatenate([c[:, r, :pay] * exp_cb[:, r:r + 1].astype(np.uint8) for r in range(enc.C)], axis=1)
+    b_hat.fill_(1)                                                          # the stage must write every byte itself
+    pkg.crc_check_dev(enc, d_c.data_ptr(), n_tb, b_hat.data_ptr(), ok.data_ptr(), cbp.data_ptr())
+    torch.cuda.synchronize()
+    assert (b_hat.cpu().numpy() == exp_b).all()
     tb_poly = enc.transport_block_CRC_polynomial
     exp_ok = np.array([int(orc.crc(tb_poly, enc.transport_block_L, exp_b[t]) == 0 and exp_cb[t].all()) for t in range(n_tb)])
     assert (cbp.cpu().numpy() == exp_cb).all()

@@ -71,3 +71,27 @@ def test_two_rank_gloo_sharding():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok and tmax == 2.0 and (lo, hi) == (0, 6)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bench_rank_protocol_runs_under_gloo():
+    """bench.py's multi-rank branch (init_process_group, barrier-bracketed timed loop, max over ranks, rank 0 prints
+    ONE JSON line) executed with two CPU processes under gloo, launched the way the driver launches it."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--dry-run"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["ms_per_step"] >= 2.0  # max over ranks: rank 1 sleeps 2 ms

@@ -34,7 +34,8 @@ def test_cfg2_bg1_z384_r13_batch4096(pkg, orc):
 
 def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):
     # G for R = 1/5 ... 2/3 -> active layers; Es/N0 about 1 dB above each waterfall
-    for E, nl, esn0 in ((19120, 42, -3.0), (11472, 22, -0.5), (7648, 12, 2.0), (5736, 7, 4.5)):
+    for E, nl, esn0 in ((19120, 42, -3.0), (15296, 32, -2.0), (11472, 22, -0.5), (9560, 17, 0.5), (7648, 12, 2.0),
+                        (6374, 9, 3.2), (5736, 7, 4.5)):  # all seven rates of BASELINE configs[2]
         bler, it = _roundtrip(pkg, orc, 2, 384, 4096, nl, E, esn0, 25, True, E)
         assert bler < 0.05, (E, bler)
         assert it.min() >= 1 and it.mean() < 20
@@ -111,10 +112,12 @@ def test_pipelined_host_path_equals_one_device_launch(pkg, orc, dt, B):
     assert (h1 != info).any(1).mean() < 0.05 and it1.min() < 12
 
 
-def test_cfg4_one_launch_per_base_graph_equals_one_launch_per_bucket(pkg, orc):
-    """nrldpc_decode_multi_dev: the mixed batch of BASELINE configuration 4 in two launches (one per base graph)
-    must return what 102 separate nrldpc_decode_dev launches return: hard bits and iteration counts, including
-    buckets of one codeword, pruned layer counts and differing iteration caps."""
+def test_cfg4_mixed_batch_in_one_call_matches_the_oracle(pkg, orc):
+    """nrldpc_decode_multi_dev on the mixed batch of BASELINE configuration 4 plus two large buckets: small buckets
+    share one launch of the run-time-Z kernel per base graph, buckets that fill the chip go to their compile-time-Z
+    kernels.  Checked against the ORACLE (two codewords of every bucket, all of the single-codeword bucket) and
+    against one nrldpc_decode_dev launch per bucket (everything): hard bits and iteration counts, including pruned
+    layer counts, differing iteration caps, fixed-iteration and early-termination configurations."""
     import torch
     rng = np.random.default_rng(44)
     draws = [(int(rng.integers(1, 3)), int(rng.choice(ALL_Z))) for _ in range(8192)]
@@ -122,25 +125,37 @@ def test_cfg4_one_launch_per_base_graph_equals_one_launch_per_bucket(pkg, orc):
     for key in draws:
         buckets[key] = buckets.get(key, 0) + 1
     buckets[(1, 7)] = 1                                            # a single-codeword bucket
-    codecs, llrs, ns, ref_h, ref_i = [], [], [], [], []
+    buckets[(1, 384)] = 600                                        # >= 512*384 rows: routed to the z64 kernels
+    buckets[(2, 256)] = 800
+    codecs, llrs, ns, ref_h, ref_i, host_llr = [], [], [], [], [], []
     s = torch.cuda.current_stream().cuda_stream
     for k, ((bg, Z), n) in enumerate(sorted(buckets.items())):
         rows, cols, kb = BG_DIMS[bg]
         nl = 0 if k % 3 else max(4, rows - (k % 11))               # some pruned layer counts
-        c = pkg.Codec(bg, Z, max_iter=12 + (k % 5), n_layers=nl, early_term=bool(k % 4), llr_dtype=np.float16, alpha=0.625)
+        c = pkg.Codec(bg, Z, max_iter=8 + (k % 5), n_layers=nl, early_term=bool(k % 4), llr_dtype=np.float16)
         info = rng.integers(0, 2, (n, kb * Z), dtype=np.uint8)
-        llr = torch.from_numpy(awgn_llr(rng, c.encode(info), 2.0, np.float16, Z)).cuda()
+        x = awgn_llr(rng, c.encode(info), 2.0, np.float16, Z)
+        llr = torch.from_numpy(x).cuda()
         h = torch.empty((n, kb * Z), dtype=torch.uint8, device="cuda")
         it = torch.empty(n, dtype=torch.int32, device="cuda")
         c.decode_dev(llr.data_ptr(), n, h.data_ptr(), it.data_ptr(), None, s)
-        codecs.append(c); llrs.append(llr); ns.append(n); ref_h.append(h); ref_i.append(it)
+        codecs.append(c); llrs.append(llr); ns.append(n); ref_h.append(h); ref_i.append(it); host_llr.append(x[:2])
     out_h = [torch.zeros_like(h) for h in ref_h]
     out_i = [torch.zeros_like(i) for i in ref_i]
     pkg.decode_multi_dev(codecs, [x.data_ptr() for x in llrs], ns, [x.data_ptr() for x in out_h],
                          [x.data_ptr() for x in out_i], s)
+    # a second call on another stream while the first may still be running: each call has its own table slot
+    s2 = torch.cuda.Stream()
+    out_h2 = [torch.zeros_like(h) for h in ref_h]
+    pkg.decode_multi_dev(codecs, [x.data_ptr() for x in llrs], ns, [x.data_ptr() for x in out_h2], None, s2.cuda_stream)
     torch.cuda.synchronize()
-    for k in range(len(codecs)):
-        assert (out_h[k] == ref_h[k]).all() and (out_i[k] == ref_i[k]).all(), (k, codecs[k].Z)
+    for k, c in enumerate(codecs):
+        assert (out_h[k] == ref_h[k]).all() and (out_i[k] == ref_i[k]).all(), (k, c.bg, c.Z)
+        assert (out_h2[k] == ref_h[k]).all(), (k, c.bg, c.Z)
+        m = min(2, ns[k])
+        ho, io = orc.decode_nmsq(c.bg, c.Z, host_llr[k][:m].astype(np.float64), 8 + (k % 5), n_layers=c.n_layers,
+                                 early_term=bool(k % 4), **rule_kw(c))
+        assert (out_h[k][:m].cpu().numpy() == ho).all() and (out_i[k][:m].cpu().numpy() == io).all(), (k, c.bg, c.Z)
     # no iteration counts requested, and an empty configuration in the middle
     out2 = [torch.zeros_like(h) for h in ref_h]
     ns2 = list(ns); ns2[3] = 0
@@ -149,3 +164,51 @@ def test_cfg4_one_launch_per_base_graph_equals_one_launch_per_bucket(pkg, orc):
     assert all((out2[k] == ref_h[k]).all() for k in range(len(codecs)) if k != 3) and int(out2[3].sum()) == 0
     for c in codecs:
         c.close()
+
+
+def test_pool_of_logical_shards_equals_one_launch(pkg, orc):
+    """nrldpc_pool_*: N handles + N host threads + a chunk queue (the in-library multi-GPU dispatcher of SURVEY 8e),
+    exercised on one GPU with four logical shards: hard bits and iteration counts of the pooled decode equal one
+    plain decode of the same batch, every codeword is decoded exactly once, and with early termination the work
+    split is whatever the queue gave (cfg5-like R = 8/9 code, half of the codewords hopeless so shards run unevenly)."""
+    rng = np.random.default_rng(8)
+    bg, Z, B = 1, 384, 3001
+    c = pkg.Codec(bg, Z, max_iter=25, n_layers=5, early_term=True, llr_dtype=np.float32)
+    info = rng.integers(0, 2, (B, c.K), dtype=np.uint8)
+    llr = awgn_llr(rng, c.encode(info), 7.5, np.float32, Z, E=9478)
+    llr[B // 2:] *= 0.05                                      # second half: never converges, 25 iterations each
+    ref_h, ref_i = c.decode(llr, want_iters=True)
+    c.close()
+    pool = pkg.CodecPool(bg, Z, [0, 0, 0, 0], chunks_per_device=4, max_iter=25, n_layers=5, early_term=True,
+                         llr_dtype=np.float32)
+    for _ in range(2):                                        # second call: the pool is reusable
+        h, it = pool.decode(llr, want_iters=True)
+        assert (h == ref_h).all() and (it == ref_i).all()
+        split = pool.last_split()
+        assert sum(split) == B and len(split) == 4 and min(split) > 0
+    assert pool.decode(llr[:1]).shape == (1, 22 * Z) and pool.decode(llr[:0]).shape == (0, 22 * Z)
+    pool.close()
+    with pytest.raises(pkg.NRLDPCError):
+        pkg.CodecPool(bg, Z, [0, 99])                         # a device that does not exist: the whole pool fails
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    """bench.py launched the way the driver launches the scaling run (torch.distributed.run, one rank per 'GPU'), with
+    both ranks on this box's single GPU and gloo for the barrier / max-over-ranks (RCCL refuses two ranks on one
+    device): the real decode path under the multi-rank protocol.  Weak scaling: 2 x batch codewords in the job."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--batch", "1024", "--backend", "gloo", "--share-gpu"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 1.0 and rec["bler"] < 0.05 and "cpu_baseline" not in rec

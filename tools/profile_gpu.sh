@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 4 --warmup 1 --cpu-sample 0 $*"
+BENCH="python $ROOT/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-e2e $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 pmc() { # name, counters...
   local name=$1; shift
