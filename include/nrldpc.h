@@ -165,6 +165,15 @@ int nrldpc_crc_check_harq_dev(const nrldpc_tb_params* p, const uint8_t* d_c_hat,
 int nrldpc_crc_attach_dev(const nrldpc_tb_params* p, const uint8_t* d_a, int32_t n_tb, uint8_t* d_c, void* stream);
 int nrldpc_rate_match_dev(const nrldpc_tb_params* p, const uint8_t* d_cw, int32_t n_tb, uint8_t* d_g, void* stream);
 
+/* Channel leg of the Monte-Carlo loop, fused: replaces step(hMod,g), step(hChan,tx),
+ * step(hDemod,rx) of plot_BLER_vs_SNR.m:130-132 -- NRModulator.m:73-81 (TS 38.211 maps, unit average power),
+ * comm.AWGNChannel at EsN0_dB (:50,105), NRDemodulator.m:76-84 (exact LLRs, Variance = 10^(-EsN0/10), :106).
+ * d_g: n_bits rate-matched bits (bytes {0,1}), n_bits a multiple of Q_m in {1,2,4,6,8}; d_g_tilde: n_bits f32 LLRs,
+ * positive = bit 0.  Noise: Philox-4x32-10 keyed by `seed`, counter = first_symbol + symbol index, Box-Muller --
+ * the same (seed, symbol) always sees the same noise, whatever the batch split.  Current HIP device. */
+int nrldpc_awgn_llr_dev(const uint8_t* d_g, int64_t n_bits, int32_t Q_m, float EsN0_dB, uint64_t seed,
+                        uint64_t first_symbol, float* d_g_tilde, void* stream);
+
 /* Kernel timing: when enabled, every *_dev / host call records HIP events around its kernel on the
  * launch stream; nrldpc_last_kernel_ms synchronises on the stop event and returns the duration. */
 int nrldpc_set_timing(nrldpc_handle h, int32_t enabled);

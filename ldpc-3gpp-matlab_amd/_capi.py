@@ -57,7 +57,7 @@ def tb_params(p):
     return t
 
 
-EXPORTS = ["nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_check_harq_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
+EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_check_harq_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
            "nrldpc_decode_multi_dev", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version", "nrldpc_build_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
@@ -109,6 +109,7 @@ def load():
     L.nrldpc_rate_recover_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, i32, vp]
     L.nrldpc_crc_check_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, vp, vp]
     L.nrldpc_crc_check_harq_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, vp, vp, i32, vp]
+    L.nrldpc_awgn_llr_dev.argtypes = [vp, C.c_int64, i32, C.c_float, C.c_uint64, C.c_uint64, vp, vp]
     L.nrldpc_crc_attach_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp]
     L.nrldpc_rate_match_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp]
     L.nrldpc_pool_create.argtypes = [C.POINTER(Cfg), C.POINTER(i32), i32, i32, C.POINTER(vp)]
@@ -308,6 +309,12 @@ def crc_check_harq_dev(p, d_c_hat, n_tb, d_b_hat, d_ok, d_cb_pass, cbgti_flags=N
         flags = (C.c_uint8 * t.C)(*[1 if f else 0 for f in cbgti_flags])
     check(load().nrldpc_crc_check_harq_dev(C.byref(t), _ptr(d_c_hat), int(n_tb), _ptr(d_b_hat), _ptr(d_ok),
                                            _ptr(d_cb_pass), flags, int(bool(keep_b_hat)), C.c_void_p(stream)))
+
+
+def awgn_llr_dev(d_g, n_bits, Q_m, EsN0_dB, seed, first_symbol, d_g_tilde, stream=0):
+    """nrldpc_awgn_llr_dev: modulation + AWGN + exact LLRs in one kernel (plot_BLER_vs_SNR.m:130-132)."""
+    check(load().nrldpc_awgn_llr_dev(_ptr(d_g), int(n_bits), int(Q_m), float(EsN0_dB), int(seed), int(first_symbol),
+                                     _ptr(d_g_tilde), C.c_void_p(stream)))
 
 
 def crc_attach_dev(p, d_a, n_tb, d_c, stream=0):

@@ -552,13 +552,14 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     if (iters_out) HIP_TRY(h->s_iters.reserve(cap));
     if (app_out) HIP_TRY(h->s_app.reserve(cap * ncw));
 
-    // Batches above 8 MB: chunks of up to ~32 MB (NRLDPC_HOST_CHUNK_MB; NRLDPC_HOST_THREADS copy threads, default 8;
+    // Batches above 8 MB: chunks of up to ~32 MB (NRLDPC_HOST_CHUNK_MB; NRLDPC_HOST_THREADS copy threads, default 4 -- measured best
+    // of 4/8/16/32 x 16/32/64 MB on the MI355X host, profiles/r02_bench_host_path.json;
     // NRLDPC_HOST_PIPELINE=0 disables) flow caller array -> pinned slot (copy threads) -> H2D -> decode -> D2H ->
     // pinned slot -> caller array on two alternating streams, so that host copies, both DMA directions and
     // the kernels of neighbouring chunks overlap.  Same kernels, same results as one launch.
     const size_t in_bytes = (size_t)batch * ncw * eb;
     static const int env_chunk_mb = getenv("NRLDPC_HOST_CHUNK_MB") ? atoi(getenv("NRLDPC_HOST_CHUNK_MB")) : 32;
-    static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 8;
+    static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 4;
     static const int env_pipe = getenv("NRLDPC_HOST_PIPELINE") ? atoi(getenv("NRLDPC_HOST_PIPELINE")) : 1;
     if (env_pipe && in_bytes >= ((size_t)8 << 20) && !app_out && !h->timing) {
         const size_t chunk_bytes = std::min<size_t>((size_t)std::max(1, env_chunk_mb) << 20, in_bytes / 4); // >= 4 chunks
@@ -893,6 +894,24 @@ int nrldpc_rate_match_dev(const nrldpc_tb_params* p, const uint8_t* d_cw, int32_
     if (off != p->G) return fail(NRLDPC_ERR_ARG, "sum(E_r) must equal G");
     hipError_t e = nrldpc::launch_rate_match(a, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hipfail(e, "rate-matching kernel launch");
+    return NRLDPC_OK;
+}
+
+int nrldpc_awgn_llr_dev(const uint8_t* d_g, int64_t n_bits, int32_t Q_m, float EsN0_dB, uint64_t seed,
+                        uint64_t first_symbol, float* d_g_tilde, void* stream) {
+    if (Q_m != 1 && Q_m != 2 && Q_m != 4 && Q_m != 6 && Q_m != 8) return fail(NRLDPC_ERR_UNSUPPORTED, "Unsupported modulation");
+    if (n_bits < 0 || n_bits % Q_m) return fail(NRLDPC_ERR_ARG, "n_bits must be a non-negative multiple of Q_m");
+    if (n_bits == 0) return NRLDPC_OK;
+    if (!d_g || !d_g_tilde) return fail(NRLDPC_ERR_ARG, "null pointer");
+    if (!(EsN0_dB > -60.0f && EsN0_dB < 80.0f)) return fail(NRLDPC_ERR_ARG, "EsN0_dB out of range");
+    nrldpc::ChanArgs a;
+    a.g = d_g; a.llr = d_g_tilde; a.n_sym = n_bits / Q_m; a.seed = seed; a.first_symbol = first_symbol; a.Qm = Q_m;
+    const double n0 = std::pow(10.0, -(double)EsN0_dB / 10.0); // plot_BLER_vs_SNR.m:106
+    static const double mean_sq[5] = {1.0, 1.0, 5.0, 21.0, 85.0};  // mean(level^2) of a rail with 0,1,2,3,4 bits
+    a.sigma = (float)std::sqrt(n0 / 2.0); a.inv_n0 = (float)(1.0 / n0);
+    a.inv_norm = (float)(1.0 / std::sqrt(2.0 * mean_sq[Q_m / 2]));
+    hipError_t e = nrldpc::launch_awgn_llr(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hipfail(e, "channel kernel launch");
     return NRLDPC_OK;
 }
 

@@ -1,0 +1,115 @@
+// nrldpc_channel.hip -- modulation + AWGN + exact-LLR demodulation fused into one kernel.
+//
+// Replaces, in the Monte-Carlo loop of plot_BLER_vs_SNR.m:130-132,
+//     tx = step(hMod, g);  rx = step(hChan, tx);  g_tilde = step(hDemod, rx);
+// i.e. NRModulator.m:73-81 (TS 38.211 Gray maps through the reference's custom symbol tables, unit average power),
+// comm.AWGNChannel at Es/N0 (plot_BLER_vs_SNR.m:50,105) and NRDemodulator.m:76-84 ('Log-likelihood ratio' = exact
+// LLRs with Variance = N0 = 10^(-EsN0/10), :106).  The symbols never exist in memory: a thread owns one symbol, reads its
+// Q_m bits (1 byte each, the boundary format of the rate-matching stage), draws its noise from a counter-based
+// generator (Philox-4x32-10, counter = global symbol index, key = seed: reproducible for any launch geometry, and
+// restated in numpy by the test oracle), and writes Q_m LLRs (f32, positive = bit 0).  HBM-bound: 1 byte in,
+// 4 bytes out per bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nrldpc_kernels.h"
+
+namespace nrldpc {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// amplitude of one I/Q rail from its NB bits, most significant (sign) first: TS 38.211 5.1.3-5.1.5,
+// 16QAM (1-2b0)(2-(1-2b2)), 64QAM (1-2b0)(4-(1-2b2)(2-(1-2b4))), 256QAM one level more
+template <int NB> __device__ __forceinline__ float pam_level(uint32_t code) {
+    float x = 1.0f;
+#pragma unroll
+    for (int j = 1; j < NB; ++j) {
+        const uint32_t b = (code >> (j - 1)) & 1u; // innermost (last) bit first
+        x = (float)(1 << j) - (b ? -x : x);
+    }
+    return ((code >> (NB - 1)) & 1u) ? -x : x;
+}
+
+template <int NB> __device__ __forceinline__ void rail_llr(float y, float inv_n0, float inv_norm, float (&llr)[NB]) {
+    float mx[NB][2], sm[NB][2];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { mx[k][0] = mx[k][1] = -3.0e38f; sm[k][0] = sm[k][1] = 0.0f; }
+    float met[1 << NB];
+#pragma unroll
+    for (uint32_t c = 0; c < (1u << NB); ++c) {
+        const float d = y - pam_level<NB>(c) * inv_norm;
+        met[c] = -d * d * inv_n0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int bit = (c >> (NB - 1 - k)) & 1u;
+            mx[k][bit] = fmaxf(mx[k][bit], met[c]);
+        }
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < (1u << NB); ++c)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int bit = (c >> (NB - 1 - k)) & 1u;
+            sm[k][bit] += expf(met[c] - mx[k][bit]);
+        }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) llr[k] = (mx[k][0] + logf(sm[k][0])) - (mx[k][1] + logf(sm[k][1]));
+}
+
+template <int QM> __global__ __launch_bounds__(256) void nrldpc_awgn_llr_kernel(const ChanArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // symbol of this launch
+    if (s >= a.n_sym) return;
+    const uint64_t gs = a.first_symbol + (uint64_t)s;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)gs, (uint32_t)(gs >> 32), 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+    // Box-Muller on 24-bit uniforms in (0,1): exact in f32
+    const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1)) * a.sigma; // sigma = sqrt(N0/2) per rail
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    const float ni = rad * cs, nq = rad * sn;
+    const uint8_t* g = a.g + s * QM;
+    float* o = a.llr + s * QM;
+    if constexpr (QM == 1) { // comm.PSKModulator order 2, phase offset pi/4 (NRModulator.m:73): LLR = 4 Re(rx e^{-j pi/4}) / N0
+        const float tx = (g[0] & 1u) ? -1.0f : 1.0f;
+        const float y = tx + (ni + nq) * 0.70710678118654752f; // noise projected onto the signalling axis
+        o[0] = 4.0f * y * a.inv_n0;
+    } else {
+        constexpr int NB = QM / 2;
+        uint32_t wi = 0, wq = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { wi = (wi << 1) | (g[2 * k] & 1u); wq = (wq << 1) | (g[2 * k + 1] & 1u); }
+        const float yi = pam_level<NB>(wi) * a.inv_norm + ni, yq = pam_level<NB>(wq) * a.inv_norm + nq;
+        float li[NB], lq[NB];
+        rail_llr<NB>(yi, a.inv_n0, a.inv_norm, li);
+        rail_llr<NB>(yq, a.inv_n0, a.inv_norm, lq);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { o[2 * k] = li[k]; o[2 * k + 1] = lq[k]; }
+    }
+}
+
+hipError_t launch_awgn_llr(const ChanArgs& a, hipStream_t stream) {
+    const dim3 grid((unsigned)((a.n_sym + 255) / 256)), block(256);
+    switch (a.Qm) {
+        case 1: hipLaunchKernelGGL(nrldpc_awgn_llr_kernel<1>, grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(nrldpc_awgn_llr_kernel<2>, grid, block, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(nrldpc_awgn_llr_kernel<4>, grid, block, 0, stream, a); break;
+        case 6: hipLaunchKernelGGL(nrldpc_awgn_llr_kernel<6>, grid, block, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL(nrldpc_awgn_llr_kernel<8>, grid, block, 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace nrldpc

@@ -585,12 +585,16 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         // fixed-iteration path: barrier groups software-pipelined (see pipeline_z64)
         if (active) {
             const float cap = (127.49f + a.beta) / a.alpha; // see track_part
+            // alpha and beta as VGPR values: the two fused multiply-adds per row then issue at the full rate (any VALU
+            // op with an SGPR operand takes 4 cycles) and need no v_mov for their second scalar operand
+            DecArgs av = a;
+            asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
             GroupZ64<BG, ZC, 0, NL> g0;
             g0.template loads<false>(lds, R);
             g0.template track<false>(st, cap);
             for (int it = 1; it <= a.max_iter; ++it) {
                 GroupZ64<BG, ZC, 0, NL> nx;
-                pipeline_z64<BG, ZC, 0, false, NL>(g0, nx, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+                pipeline_z64<BG, ZC, 0, false, NL>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
                 g0 = nx;
             }
         } else {
@@ -634,6 +638,8 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         // whose codeword has converged (or does not exist) drops into the second loop and only keeps the
         // barrier count of its workgroup until every codeword of it is done.
         const float cap = (127.49f + a.beta) / a.alpha;
+        DecArgs av = a; // see the fixed-iteration path
+        asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
         int it = 1;
         bool all_done = false;
         if (active) {
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             for (; it <= a.max_iter; ++it) {
                 esign_lo = 0; esign_hi = 0;
                 GroupZ64<BG, ZC, 0, NL> nx;
-                pipeline_z64<BG, ZC, 0, true, NL>(g0, nx, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+                pipeline_z64<BG, ZC, 0, true, NL>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
                 g0 = nx;
                 all_done = parity_pass(it);
                 if (all_done || done) { ++it; break; }

@@ -127,5 +127,15 @@ struct TxRmArgs {
 };
 hipError_t launch_rate_match(const TxRmArgs& a, hipStream_t stream);
 
+struct ChanArgs {
+    const uint8_t* g;   // [n_sym * Qm] bits, one per byte
+    float* llr;         // [n_sym * Qm] exact LLRs, positive = bit 0
+    int64_t n_sym;
+    uint64_t seed, first_symbol;
+    int32_t Qm;
+    float sigma, inv_n0, inv_norm; // sqrt(N0/2); 1/N0; 1/sqrt(2 mean(level^2)) of one rail
+};
+hipError_t launch_awgn_llr(const ChanArgs& a, hipStream_t stream);
+
 } // namespace nrldpc
 #endif

@@ -114,11 +114,13 @@ def demodulate_llr_t(rx, Q_m, N0):
     return out.reshape(rx.shape[:-1] + (-1,))
 
 
-def simulate_point_device(enc_chain, dec_chain, Q_m, EsN0, rv_id_sequence, batch, gen):
+def simulate_point_device(enc_chain, dec_chain, Q_m, EsN0, rv_id_sequence, batch, gen, chan=None):
     """simulate_point with every stage on the GPU (rows N1-N4 of SURVEY.md section 8f): payload RNG, CRC
-    attachment, encoding, rate matching, modulation, AWGN, exact LLRs, rate recovery, decoding, CRC
-    check, error count.  enc_chain / dec_chain share one NRLDPC parameter object."""
+    attachment, encoding, rate matching, modulation + AWGN + exact LLRs (one HIP kernel, nrldpc_awgn_llr_dev),
+    rate recovery, decoding, CRC check, error count.  enc_chain / dec_chain share one NRLDPC parameter object.
+    chan: [seed, symbols drawn so far] of the channel's counter-based noise generator (advanced here)."""
     import torch
+    from ._capi import awgn_llr_dev
     p = enc_chain.p
     dev = enc_chain.dev
     a = torch.randint(0, 2, (batch, p.A), generator=gen, device=dev, dtype=torch.uint8)   # :118
@@ -129,11 +131,18 @@ def simulate_point_device(enc_chain, dec_chain, Q_m, EsN0, rv_id_sequence, batch
     for rv in rv_id_sequence:                                                              # :124-137
         p.rv_id = rv
         g = enc_chain.step(a)
-        tx = modulate_t(g, Q_m)
-        noise = (N0 / 2.0) ** 0.5 * torch.complex(
-            torch.randn(tx.shape, generator=gen, device=dev, dtype=torch.float64),
-            torch.randn(tx.shape, generator=gen, device=dev, dtype=torch.float64))
-        g_tilde = demodulate_llr_t(tx + noise, Q_m, N0).float()
+        if chan is not None:                                                               # :130-132 in one kernel
+            g_tilde = torch.empty(g.shape, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                awgn_llr_dev(g.data_ptr(), g.numel(), Q_m, EsN0, chan[0], chan[1], g_tilde.data_ptr(),
+                             torch.cuda.current_stream(dev).cuda_stream)
+            chan[1] += g.numel() // Q_m
+        else:  # torch elementwise restatement (float64), kept as the cross-check of the kernel
+            tx = modulate_t(g, Q_m)
+            noise = (N0 / 2.0) ** 0.5 * torch.complex(
+                torch.randn(tx.shape, generator=gen, device=dev, dtype=torch.float64),
+                torch.randn(tx.shape, generator=gen, device=dev, dtype=torch.float64))
+            g_tilde = demodulate_llr_t(tx + noise, Q_m, N0).float()
         dec, good, _ = dec_chain.step(g_tilde)
         newly = good & ~ok
         a_hat[newly] = dec[newly]
@@ -212,13 +221,14 @@ def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0
                         rx_chain = DeviceDecodeChain(shared, iterations=iterations, I_HARQ=1, **(decoder_kwargs or {}))
                         gen = torch.Generator(device="cuda")
                         gen.manual_seed(int(seed))
+                        chan = [int(seed) * 0x9E3779B97F4A7C15 % (1 << 64), 0]  # noise stream of this curve
                     with open(os.path.join(results_dir, name), "w") as fid:
                         BLER, EsN0, found_start = 1.0, float(EsN0_start), False                          # :84-88
                         while BLER > target_BLER and len(points) < max_points:                           # :104
                             blocks = errors = 0
                             keep_going = True
                             while keep_going and errors < target_block_errors:                           # :116
-                                outcomes = (simulate_point_device(tx_chain, rx_chain, Q_m, EsN0, rv_id_sequence, batch, gen)
+                                outcomes = (simulate_point_device(tx_chain, rx_chain, Q_m, EsN0, rv_id_sequence, batch, gen, chan)
                                             if device else simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng))
                                 for good in outcomes:
                                     if not found_start and not good:                                     # :139-141

@@ -168,3 +168,39 @@ def test_device_stages_reproduce_committed_vectors(pkg):
         torch.cuda.synchronize()
         got, ref = out.cpu().numpy(), g[name + "/rate_recovered"]
         assert (np.isinf(got) == np.isinf(ref)).all() and (got[~np.isinf(ref)] == ref[~np.isinf(ref)]).all(), name
+
+
+@pytest.mark.parametrize("Q_m,esn0", [(1, -2.0), (2, 0.0), (2, 30.0), (4, 8.0), (6, 14.0), (8, 20.0), (8, 45.0)])
+def test_channel_kernel_matches_numpy_restatement(pkg, Q_m, esn0):
+    """nrldpc_awgn_llr_dev (modulation + AWGN + exact LLRs fused, plot_BLER_vs_SNR.m:130-132) vs oracle/channel_oracle.py:
+    same Philox counters, float64 math.  Tolerance (stated): |dLLR| <= 5e-4 * max(1, |LLR|) -- the kernel runs float32
+    logf / sincosf / expf; signs of every LLR above the tolerance agree.  The noise must not depend on how the symbols are
+    split over launches (first_symbol)."""
+    import torch
+    import channel_oracle as CO
+    rng = np.random.default_rng(Q_m)
+    n_sym = 20011
+    g = rng.integers(0, 2, n_sym * Q_m, dtype=np.uint8)
+    d_g = torch.from_numpy(g).cuda()
+    out = torch.empty(n_sym * Q_m, dtype=torch.float32, device="cuda")
+    seed, first = 0xC0DE1234ABCD, (1 << 32) - 5000            # the counter crosses 2^32 inside the launch
+    pkg.awgn_llr_dev(d_g.data_ptr(), g.size, Q_m, esn0, seed, first, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float64)
+    ref = CO.awgn_llr(g, Q_m, esn0, seed, first)
+    tol = 5e-4 * np.maximum(1.0, np.abs(ref))
+    assert np.isfinite(got).all() and (np.abs(got - ref) <= tol).all(), float(np.abs(got - ref).max())
+    # two launches over the halves give the same LLRs as one launch
+    h = (n_sym // 2) * Q_m
+    out2 = torch.empty_like(out)
+    pkg.awgn_llr_dev(d_g.data_ptr(), h, Q_m, esn0, seed, first, out2.data_ptr())
+    pkg.awgn_llr_dev(d_g.data_ptr() + h, g.size - h, Q_m, esn0, seed, first + n_sym // 2, out2.data_ptr() + 4 * h)
+    torch.cuda.synchronize()
+    assert (out2 == out).all()
+    # statistics of the hard decisions: bit error rate of the LLR signs within 4 sigma of the oracle's
+    ber_g, ber_r = float(((got < 0) != (g == 1)).mean()), float(((ref < 0) != (g == 1)).mean())
+    assert abs(ber_g - ber_r) <= 1e-3
+    with pytest.raises(pkg.UnsupportedParameters):
+        pkg.awgn_llr_dev(d_g.data_ptr(), 30, 3, 0.0, 1, 0, out.data_ptr())      # 8PSK: NRModulator.m:81
+    with pytest.raises(pkg.NRLDPCError):
+        pkg.awgn_llr_dev(d_g.data_ptr(), 7, 2, 0.0, 1, 0, out.data_ptr())

@@ -19,7 +19,15 @@ typedef struct {
     float alpha[46];
     float c0, c1, beta;
     int scale, msg_max, app_max; /* app_max 0 = unclamped */
+    int fp8;                     /* 1: message magnitudes rounded to the OCP e4m3 grid (4 significant bits), ties to even */
 } nms_params;
+
+static float q_e4m3(float x) { /* x >= 0 integer-valued */
+    if (x <= 16.f) return x;
+    int e; frexpf(x, &e);              /* x = f * 2^e, f in [0.5,1) -> 4 significant bits: step 2^(e-4) */
+    float step = ldexpf(1.f, e - 4);
+    return nearbyintf(x / step) * step; /* nearbyint: ties to even */
+}
 
 typedef struct { int nrows, ncols, kb, nnz; const uint16_t* row_ptr; const uint8_t* col; int shift[NR_BG1_NNZ]; } graph;
 
@@ -68,6 +76,7 @@ static int one(const graph* g, int Z, int n_layers, int max_iter, const nms_para
                 float M1 = nearbyintf(P->alpha[l] * a1) - P->beta, M2 = nearbyintf(P->alpha[l] * m2) - P->beta;
                 if (M1 < 0) M1 = 0; if (M2 < 0) M2 = 0;
                 if (M1 > P->msg_max) M1 = (float)P->msg_max; if (M2 > P->msg_max) M2 = (float)P->msg_max;
+                if (P->fp8) { M1 = q_e4m3(M1); M2 = q_e4m3(M2); }
                 for (int j = 0; j < deg; ++j) {
                     float mag = (fabsf(t[j]) == m1) ? M2 : M1;
                     float r = ((t[j] < 0) ^ S) ? -mag : mag;

@@ -19,7 +19,7 @@ L = C.CDLL(os.path.join(HERE, "libnmsf.so"))
 
 class P(C.Structure):
     _fields_ = [("alpha", C.c_float * 46), ("c0", C.c_float), ("c1", C.c_float), ("beta", C.c_float),
-                ("scale", C.c_int), ("msg_max", C.c_int), ("app_max", C.c_int)]
+                ("scale", C.c_int), ("msg_max", C.c_int), ("app_max", C.c_int), ("fp8", C.c_int)]
 
 
 L.nmsf_decode.argtypes = [C.c_int] * 4 + [C.POINTER(P), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -71,7 +71,7 @@ def bp_ref(case, snr, nblk, iters):
     return r
 
 
-def run(case, snr, nblk, alpha, c0=0.0, c1=0.0, beta=0.0, scale=8, msg_max=127, app_max=0, iters=None):
+def run(case, snr, nblk, alpha, c0=0.0, c1=0.0, beta=0.0, scale=8, msg_max=127, app_max=0, iters=None, fp8=0):
     bg, Z, Kp, E, nl, it0, _ = CASES[case]
     iters = iters or it0
     info, llr = make_llr(case, snr, nblk)
@@ -79,7 +79,7 @@ def run(case, snr, nblk, alpha, c0=0.0, c1=0.0, beta=0.0, scale=8, msg_max=127, 
     al = np.broadcast_to(np.asarray(alpha, np.float32), (46,)) if np.ndim(alpha) == 0 else np.asarray(alpha, np.float32)
     for i in range(46):
         p.alpha[i] = float(al[i]) if i < len(al) else float(al[-1])
-    p.c0, p.c1, p.beta, p.scale, p.msg_max, p.app_max = c0, c1, beta, scale, msg_max, app_max
+    p.c0, p.c1, p.beta, p.scale, p.msg_max, p.app_max, p.fp8 = c0, c1, beta, scale, msg_max, app_max, fp8
     rows, cols, kb = O.BG_DIMS[bg]
     hard = np.zeros((nblk, kb * Z), np.uint8)
     its = np.zeros(nblk, np.int32)

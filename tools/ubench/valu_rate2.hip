@@ -68,7 +68,27 @@ template <int OP> __global__ __launch_bounds__(256) void k(uint32_t* out, int it
         else if constexpr (OP == 56) asm volatile("v_sub_u16 %0, %1, %0" : "+v"(r) : "v"(c)); \
         else if constexpr (OP == 57) asm volatile("v_pk_sub_i16 %0, %1, %0" : "+v"(r) : "v"(c)); \
         else if constexpr (OP == 58) asm volatile("v_med3_i16 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(b)); \
-        else if constexpr (OP == 59) asm volatile("v_min_i16 %0, %1, %0" : "+v"(r) : "v"(c));
+        else if constexpr (OP == 59) asm volatile("v_min_i16 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 60) asm volatile("v_cvt_pk_f32_fp8 %0, %1" : "=v"(p##r) : "v"(r)); \
+        else if constexpr (OP == 61) asm volatile("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_1" : "=v"(p##r) : "v"(r)); \
+        else if constexpr (OP == 62) asm volatile("v_cvt_scalef32_pk_f32_fp8 %0, %1, 1.0 op_sel:[1,0,0]" : "=v"(p##r) : "v"(r)); \
+        else if constexpr (OP == 63) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 64) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 65) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 66) asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 67) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 68) asm volatile("v_min_f16 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 69) asm volatile("v_max_f16 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 70) asm volatile("v_min_u16 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 71) asm volatile("v_cmp_lt_u16 vcc, %1, %0" : : "v"(r), "v"(c) : "vcc"); \
+        else if constexpr (OP == 72) asm volatile("v_cvt_f32_fp8_sdwa %0, %0 src0_sel:BYTE_2" : "+v"(r)); \
+        else if constexpr (OP == 73) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(r) : "v"(c), "v"(b)); \
+        else if constexpr (OP == 74) asm volatile("v_max_i16 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 75) asm volatile("v_add_f16 %0, %1, %0" : "+v"(r) : "v"(c)); \
+        else if constexpr (OP == 76) asm volatile("v_cmp_eq_f16 vcc, %1, %0" : : "v"(r), "v"(c) : "vcc"); \
+        else if constexpr (OP == 77) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(r)); \
+        else if constexpr (OP == 78) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(r)); \
+        else if constexpr (OP == 79) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(r) : "v"(c), "v"(b));
         REP8(ONE(a0) ONE(a1) ONE(a2) ONE(a3) ONE(a4) ONE(a5) ONE(a6) ONE(a7))
     }
     f2 ps = pa0 + pa1 + pa2 + pa3 + pa4 + pa5 + pa6 + pa7;
@@ -148,5 +168,25 @@ int main() {
     run<57>("v_pk_sub_i16", d, blocks, it);
     run<58>("v_med3_i16", d, blocks, it);
     run<59>("v_min_i16", d, blocks, it);
+    run<60>("v_cvt_pk_f32_fp8 (2 regs out)", d, blocks, it);
+    run<61>("v_cvt_pk_f32_fp8_sdwa WORD_1", d, blocks, it);
+    run<62>("v_cvt_scalef32_pk_f32_fp8 opsel", d, blocks, it);
+    run<63>("v_cvt_pk_fp8_f32 hi", d, blocks, it);
+    run<64>("v_cvt_pk_fp8_f32 lo", d, blocks, it);
+    run<65>("v_fma_mix_f32", d, blocks, it);
+    run<66>("v_dot4_i32_i8", d, blocks, it);
+    run<67>("v_dot2c_f32_bf16", d, blocks, it);
+    run<68>("v_min_f16", d, blocks, it);
+    run<69>("v_max_f16", d, blocks, it);
+    run<70>("v_min_u16", d, blocks, it);
+    run<71>("v_cmp_lt_u16", d, blocks, it);
+    run<72>("v_cvt_f32_fp8_sdwa", d, blocks, it);
+    run<73>("v_dot2_f32_f16", d, blocks, it);
+    run<74>("v_max_i16", d, blocks, it);
+    run<75>("v_add_f16", d, blocks, it);
+    run<76>("v_cmp_eq_f16", d, blocks, it);
+    run<77>("v_cvt_f32_f16", d, blocks, it);
+    run<78>("v_cvt_f16_f32", d, blocks, it);
+    run<79>("v_cndmask_b32 (independent dst)", d, blocks, it);
     return 0;
 }
