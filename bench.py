@@ -295,7 +295,7 @@ def main():
                        "sharding": "codeword batches per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "nrldpc::nrldpc_decode_z64_kernel<1, 384, 2, true, true, false>", "kernel_ms": kernel_ms,
+                         "kernel": "nrldpc::nrldpc_decode_z64_kernel<1, 384, 2, true, true, false, 46>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_codeword": ALG_BYTES_PER_CW, "storage_bytes_per_message": S_BYTES,
                          "hbm_achieved_GBs_from_traffic": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "hbm_frac_from_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,

@@ -42,6 +42,10 @@ template <int NB> __device__ __forceinline__ float pam_level(uint32_t code) {
 }
 
 template <int NB> __device__ __forceinline__ void rail_llr(float y, float inv_n0, float inv_norm, float (&llr)[NB]) {
+    if constexpr (NB == 1) { // two points +-p: log-sum-exp of one term each, ((y+p)^2 - (y-p)^2)/N0 = 4 p y / N0
+        llr[0] = 4.0f * inv_norm * y * inv_n0;
+        return;
+    }
     float mx[NB][2], sm[NB][2];
 #pragma unroll
     for (int k = 0; k < NB; ++k) { mx[k][0] = mx[k][1] = -3.0e38f; sm[k][0] = sm[k][1] = 0.0f; }

@@ -9,6 +9,7 @@ Algorithmic bytes (every stage is a pure gather / scatter, HBM-bound):
   crc_attach    read A bytes + write C*K bytes
   encode        read C*K bytes + write C*(N+2Z) bytes
   rate_match    read G selected code bits + write G bytes
+  awgn_llr      read G bytes + write G f32 LLRs (noise is generated in registers)
 """
 import importlib
 import json
@@ -61,6 +62,9 @@ def run(name, n_tb, harq, **props):
     rec("crc_attach", timed(lambda: capi.crc_attach_dev(t, a.data_ptr(), n_tb, c.data_ptr(), s)), n_tb * (A + C * K))
     rec("encode", timed(lambda: codec.encode_dev(c.data_ptr(), n_tb * C, cw.data_ptr(), s)), n_tb * C * (K + ncwz))
     rec("rate_match", timed(lambda: capi.rate_match_dev(t, cw.data_ptr(), n_tb, g.data_ptr(), s)), n_tb * 2 * G)
+    g_ch = torch.empty((n_tb, G), device="cuda", dtype=torch.float32)
+    rec("awgn_llr (modulate + AWGN + exact LLR)", timed(lambda: capi.awgn_llr_dev(g.data_ptr(), n_tb * G, props["Q_m"], 3.0, 11, 0,
+                                                                            g_ch.data_ptr(), s)), n_tb * 5 * G)
     g_tilde = (1.0 - 2.0 * g.float()) * 4.0
     llr = torch.empty((n_tb * C, ncwz), device="cuda", dtype=torch.float16)
     rec("rate_recover", timed(lambda: capi.rate_recover_dev(t, g_tilde.data_ptr(), n_tb, None, llr.data_ptr(),

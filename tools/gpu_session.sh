@@ -1,10 +1,12 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_chain_gpu.py tests/test_harness_gpu.py tests/test_decode_gpu.py -x -q -m gpu 2>&1 | tail -15 > gpurun_out/s9_tests.txt
-cat gpurun_out/s9_tests.txt
-python tools/bench_one.py 1 384 4096 0 0 25 2>&1 | grep -v amdgpu
-python tools/bench_host_path.py --sweep > gpurun_out/s9_host_sweep.txt 2>&1
-grep -h batch gpurun_out/s9_host_sweep.txt | python -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l); print(d['llr_dtype'], 'th',d['host_threads'],'mb',d['chunk_mb'], 'min %.2f med %.2f max %.2f first %.1f'%(d['ms_min'],d['ms_median'],d['ms_max'],d['ms_first_call']))"
+bash tools/profile_gpu.sh r02 > gpurun_out/s10_profile.log 2>&1
+python bench.py > gpurun_out/s10_bench.txt 2>gpurun_out/s10_bench.err
+python tools/bench_configs.py > gpurun_out/s10_cfg.txt 2>&1
+python tools/bench_all_z.py > gpurun_out/s10_allz.txt 2>&1
+python tools/bench_chain.py > gpurun_out/s10_chain.txt 2>&1
+python tools/bench_host_path.py > gpurun_out/s10_host.txt 2>&1
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_chain -o chain -- python $GRAFT_REPO_ROOT/tools/bench_chain.py > $GRAFT_REPO_ROOT/gpurun_out/s10_chain_prof.log 2>&1
+cd $GRAFT_REPO_ROOT
+tail -c 600 gpurun_out/s10_bench.txt; tail -2 gpurun_out/s10_chain.txt | cut -c1-300; tail -3 gpurun_out/s10_host.txt
+ls gpurun_out/prof_chain
