@@ -57,3 +57,18 @@ def test_on_device_monte_carlo(pkg, tmp_path):
                            target_block_errors=10, target_BLER=0.1, EsN0_start=6.0, EsN0_delta=1.0, seed=4,
                            results_dir=str(tmp_path), batch=128, device=True)[(1000, 0.5, 1)]
     assert q and q[-1][1] <= 0.1
+
+
+def test_result_files_match_committed_fixture(pkg):
+    """The whole Monte-Carlo run is reproducible (numpy PCG64 payloads and noise, bit-exact decoder core): the result
+    files of two seeded sweeps -- QPSK single transmission; 16QAM with a HARQ retransmission and two payload sizes --
+    must equal tests/golden/harness_golden.json, which was generated WITHOUT a GPU by the same harness over
+    oracle-backed System objects (tests/golden/make_harness_golden.py): same SNR points, same block counts, every digit."""
+    import json
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import make_harness_golden as M
+    want = json.load(open(os.path.join(gold, "harness_golden.json")))
+    got = M.run_all()                      # the product's GPU-backed NRLDPCEncoder / NRLDPCDecoder
+    assert got == want
