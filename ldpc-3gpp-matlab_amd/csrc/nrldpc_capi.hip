@@ -4,6 +4,8 @@
 // launch directly on caller-owned device memory.  No CPU fallback exists anywhere in this library:
 // every decode/encode is a HIP kernel launch, and any HIP failure is reported as NRLDPC_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cmath>
@@ -94,6 +96,37 @@ struct PinBuf {
 
 // A few persistent host threads that move (and, for MATLAB doubles, narrow) the caller's pageable arrays
 // into / out of the pinned staging buffers: one core does not keep up with PCIe.
+// CPUs of the NUMA node the calling thread runs on (/sys/devices/system/node/node*/cpulist), empty if unknown.  The
+// caller's arrays were most likely first touched -- hence placed -- there; copy threads that wander to the other
+// socket of a two-socket host made the MATLAB-double path swing between 12 and 19 ms from one process to the next.
+static bool caller_node_cpus(cpu_set_t* out) {
+    const int me = sched_getcpu();
+    if (me < 0) return false;
+    for (int node = 0; node < 64; ++node) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        FILE* f = fopen(path, "r");
+        if (!f) break;
+        char buf[4096];
+        const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+        fclose(f);
+        if (!ok) continue;
+        CPU_ZERO(out);
+        bool mine = false;
+        for (char* p = buf; *p && *p != '\n';) { // "0-63,128-191"
+            char* e;
+            const long a = strtol(p, &e, 10);
+            long b = a;
+            if (*e == '-') b = strtol(e + 1, &e, 10);
+            for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, out); mine |= (c == me); }
+            p = (*e == ',') ? e + 1 : e;
+            if (e == p && *e != ',') break;
+        }
+        if (mine) return true;
+    }
+    return false;
+}
+
 class HostPool {
     std::vector<std::thread> th_;
     std::mutex m_;
@@ -105,8 +138,11 @@ class HostPool {
 
 public:
     explicit HostPool(int n) {
+        cpu_set_t node;
+        const bool pin = getenv("NRLDPC_HOST_NO_PIN") == nullptr && caller_node_cpus(&node);
         for (int i = 0; i < n; ++i)
-            th_.emplace_back([this, i, n] {
+            th_.emplace_back([this, i, n, pin, node] {
+                if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof node, &node);
                 unsigned seen = 0;
                 for (;;) {
                     std::function<void(int, int)> f;
@@ -552,14 +588,14 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     if (iters_out) HIP_TRY(h->s_iters.reserve(cap));
     if (app_out) HIP_TRY(h->s_app.reserve(cap * ncw));
 
-    // Batches above 8 MB: chunks of up to ~32 MB (NRLDPC_HOST_CHUNK_MB; NRLDPC_HOST_THREADS copy threads, default 4 -- measured best
-    // of 4/8/16/32 x 16/32/64 MB on the MI355X host, profiles/r02_bench_host_path.json;
+    // Batches above 8 MB: chunks of up to ~32 MB (NRLDPC_HOST_CHUNK_MB; NRLDPC_HOST_THREADS copy threads, default 8, pinned to the
+    // caller's NUMA node unless NRLDPC_HOST_NO_PIN is set;
     // NRLDPC_HOST_PIPELINE=0 disables) flow caller array -> pinned slot (copy threads) -> H2D -> decode -> D2H ->
     // pinned slot -> caller array on two alternating streams, so that host copies, both DMA directions and
     // the kernels of neighbouring chunks overlap.  Same kernels, same results as one launch.
     const size_t in_bytes = (size_t)batch * ncw * eb;
     static const int env_chunk_mb = getenv("NRLDPC_HOST_CHUNK_MB") ? atoi(getenv("NRLDPC_HOST_CHUNK_MB")) : 32;
-    static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 4;
+    static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 8;
     static const int env_pipe = getenv("NRLDPC_HOST_PIPELINE") ? atoi(getenv("NRLDPC_HOST_PIPELINE")) : 1;
     if (env_pipe && in_bytes >= ((size_t)8 << 20) && !app_out && !h->timing) {
         const size_t chunk_bytes = std::min<size_t>((size_t)std::max(1, env_chunk_mb) << 20, in_bytes / 4); // >= 4 chunks
