@@ -62,7 +62,8 @@ typedef struct nrldpc_cfg {
     int32_t device_id;  /* HIP device ordinal                                                      */
     int32_t max_batch;  /* staging capacity of the host entry points; 0 = grow on demand          */
     float beta;         /* min-sum offset in LLR units (>= 0), read only when alpha != 0: message magnitude =
-                           max(alpha*min - beta, 0) on the fixed-point grid; 0 = plain normalised min-sum       */
+                           max(alpha*min - beta, 0) on the fixed-point grid; 0 = plain normalised min-sum; rounded to
+                           the nearest 1/(2*llr_scale) LLR (nrldpc_get_dims reports the value in use)               */
 } nrldpc_cfg;
 
 /* Dimensions implied by (bg, Z): ncols*Z LLRs in, K = kb*Z hard bits out. */

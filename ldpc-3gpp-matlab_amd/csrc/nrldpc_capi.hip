@@ -394,7 +394,9 @@ int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
     if (!h) return fail(NRLDPC_ERR_NOMEM, "host allocation failed");
     h->cfg = *cfg;
     h->alpha = alpha;
-    h->beta = beta;
+    // the offset lives on a grid of half fixed-point units (1/(2*llr_scale) LLR): the pipelined kernels round
+    // alpha*m - beta inside one fused multiply-add against 2^23 - beta*scale, which has to be exact
+    h->beta = std::nearbyint(2.0f * beta * (float)scale) / (2.0f * (float)scale);
     h->scale = scale;
     if (!nrldpc::build_schedule(cfg->bg, cfg->Z, cfg->n_layers, &h->sched)) {
         delete h;

@@ -70,8 +70,8 @@ __device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zb, 
     }
     // magnitudes carrying the row's sign parity; the edge's own sign is xor-ed in per edge
     const uint32_t Sm = S & 0x80000000u;
-    const float M1 = __uint_as_float(fbits(scale_mag<false>(a, m1)) | Sm);
-    const float M2 = __uint_as_float(fbits(scale_mag<false>(a, m2)) | Sm);
+    const float M1 = __uint_as_float(fbits(scale_mag(a, m1)) | Sm);
+    const float M2 = __uint_as_float(fbits(scale_mag(a, m2)) | Sm);
     static_for<ncore>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);

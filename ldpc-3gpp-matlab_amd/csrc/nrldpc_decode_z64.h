@@ -72,6 +72,10 @@ template <int BG, int ZC, int NL> constexpr int z64_ncwg_nl() {
     return (BG == 1 && z64_nwv(ZC) == 6 && NL <= 6) ? 1 : z64_ncwg<BG, ZC>();
 }
 
+// Extension LLRs as floats in VGPRs (DecState::xf) for the fixed-iteration builds with register room: BG1 shapes sized
+// for 3 waves per SIMD (168 VGPRs allowed, ~130 used) with every row active.
+template <int BG, int ZC, int NCWG, int NL> constexpr bool z64_ext_float();
+
 // Early-termination builds: the codewords of a workgroup leave the decoding loop at different iterations and the
 // workgroup lives until the last one; with one codeword per workgroup nothing waits.  Measured at waterfall points
 // (QPSK/AWGN, mean 7.4-7.9 iterations): BG1 four-wave codewords (Z = 256) +9 %; six-wave codewords lose 12-50 % as
@@ -190,7 +194,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct Layer
         for (int i = 0; i < j; ++i) n += (is_late(i) == LATE);
         return n;
     }
-    template <bool LATE> __device__ __forceinline__ void track_part(const DecState<BG>& st, float cap) {
+    template <bool LATE, bool XF = false> __device__ __forceinline__ void track_part(const DecState<BG>& st, float cap) {
         // cap = (127.49 + beta)/alpha: the search starts from it, so alpha*m - beta never rounds above 127 and needs no upper clamp
         if constexpr (!LATE) { pm1 = cap; pm2 = cap; pS = 0; }
         uint32_t pend = 0;
@@ -209,7 +213,8 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct Layer
         });
         constexpr int npart = part_count_before<LATE>(ncore);
         if constexpr (!LATE && HAS_EXT) { // the extension bit is thread-private: always "early"
-            lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
+            if constexpr (XF) lam = st.xf[L - 4];
+            else lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
             const float al = fabsf(lam);
             pm2 = __builtin_amdgcn_fmed3f(al, pm1, pm2);
             pm1 = fminf(pm1, al);
@@ -223,8 +228,9 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct Layer
     __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         m1 = pm1;
         // magnitudes carrying the row's sign parity: M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
-        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag<true>(a, pm1)), pS, 0x80000000u, 0xF8));
-        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag<true>(a, pm2)), pS, 0x80000000u, 0xF8));
+        // a.beta holds 2^23 - beta here (set up by the pipelined kernels, see scale_mag_magic)
+        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag_magic(a.alpha, a.beta, pm1)), pS, 0x80000000u, 0xF8));
+        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag_magic(a.alpha, a.beta, pm2)), pS, 0x80000000u, 0xF8));
         bool ismin[ncore]; // all compares first: keeps v_cmp -> v_cndmask hazard slots filled with useful work
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -272,8 +278,8 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct Layer
         m1 = mm1;
         // magnitudes carrying the row's sign parity (M | (S & signbit), one v_bitop3_b32); the edge's own sign is
         // xor-ed in per edge
-        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag<false>(a, mm1)), S, 0x80000000u, 0xF8));
-        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag<false>(a, mm2)), S, 0x80000000u, 0xF8));
+        M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag(a, mm1)), S, 0x80000000u, 0xF8));
+        M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag(a, mm2)), S, 0x80000000u, 0xF8));
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int ce = ce0 + j;
@@ -376,10 +382,10 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS> struct GroupZ64 {
         if constexpr (N > 1) l1.template load_part<LATE>(lds, R);
         if constexpr (N > 2) l2.template load_part<LATE>(lds, R);
     }
-    template <bool LATE> __device__ __forceinline__ void track(const DecState<BG>& st, float cap) {
-        l0.template track_part<LATE>(st, cap);
-        if constexpr (N > 1) l1.template track_part<LATE>(st, cap);
-        if constexpr (N > 2) l2.template track_part<LATE>(st, cap);
+    template <bool LATE, bool XF = false> __device__ __forceinline__ void track(const DecState<BG>& st, float cap) {
+        l0.template track_part<LATE, XF>(st, cap);
+        if constexpr (N > 1) l1.template track_part<LATE, XF>(st, cap);
+        if constexpr (N > 2) l2.template track_part<LATE, XF>(st, cap);
     }
     __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         l0.finish(st, lds, R, a);
@@ -406,7 +412,7 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS> struct GroupZ64 {
 // Returns (through `next0`) group 0 with its early part done for the following iteration.
 // ET: also record the sign of every extension-parity bit's a-posteriori value (the parity pass of the
 // early-termination kernel needs it).
-template <int BG, int ZC, int GI, bool ET = false, int NL = BGT<BG>::ROWS>
+template <int BG, int ZC, int GI, bool ET = false, int NL = BGT<BG>::ROWS, bool XF = false>
 __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, GroupZ64<BG, ZC, 0, NL>& next0, DecState<BG>& st,
                                              char* lds, const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB,
                                              int w, const DecArgs& a, float cap, uint32_t& esign_lo,
@@ -426,8 +432,8 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
             // sign computations (with lam, m1, M1, M2 of every row kept alive in scratch) down to it
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
         }
-        nxt.template track<false>(st, cap);
-        pipeline_z64<BG, ZC, GI + 1, ET, NL>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+        nxt.template track<false, XF>(st, cap);
+        pipeline_z64<BG, ZC, GI + 1, ET, NL, XF>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
     } else {
         next0.template loads<false>(lds, R);
         cur.template track<true>(st, cap);
@@ -437,7 +443,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
             cur.ext(a, esign_lo, esign_hi);
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
         }
-        next0.template track<false>(st, cap);
+        next0.template track<false, XF>(st, cap);
     }
 }
 
@@ -466,6 +472,13 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
 //        per-thread `done` predicate, no extension-bit bookkeeping, no parity pass.
 // ETP  : FULL with early termination (no soft output): the pipelined iteration of PLAIN plus the sign of every
 //        extension-parity bit, then the parity pass; a finished codeword's waves only keep the barriers.
+template <int BG, int ZC, int NCWG, int NL> constexpr bool z64_ext_float() {
+#ifdef NRLDPC_Z64_XF
+    return NRLDPC_Z64_XF != 0;
+#endif
+    return BG == 1 && NL == BGT<BG>::ROWS && z64_wpe<BG, ZC, NCWG, NL>() == 3;
+}
+
 // NL   : the compile-time layer count of a FULL build: all rows, or one of the pruned counts of NRLDPC_Z64_NL_LIST
 //        (the rate-matching points BASELINE.json names), each with its own barrier-group table and prefetch plan.
 template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false, int NL = BGT<BG>::ROWS>
@@ -599,13 +612,21 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             // alpha and beta as VGPR values: the two fused multiply-adds per row then issue at the full rate (any VALU
             // op with an SGPR operand takes 4 cycles) and need no v_mov for their second scalar operand
             DecArgs av = a;
+            av.beta = 8388608.0f - a.beta; // see scale_mag_magic
             asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
+            constexpr bool XF = z64_ext_float<BG, ZC, NCWG, NL>();
+            if constexpr (XF) {
+                static_for<G::NEXT>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    st.xf[i] = byte_to_f32<i & 3>(st.xq[i >> 2]);
+                });
+            }
             GroupZ64<BG, ZC, 0, NL> g0;
             g0.template loads<false>(lds, R);
-            g0.template track<false>(st, cap);
+            g0.template track<false, XF>(st, cap);
             for (int it = 1; it <= a.max_iter; ++it) {
                 GroupZ64<BG, ZC, 0, NL> nx;
-                pipeline_z64<BG, ZC, 0, false, NL>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
+                pipeline_z64<BG, ZC, 0, false, NL, XF>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
                 g0 = nx;
             }
         } else {
@@ -650,6 +671,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         // barrier count of its workgroup until every codeword of it is done.
         const float cap = (127.49f + a.beta) / a.alpha;
         DecArgs av = a; // see the fixed-iteration path
+        av.beta = 8388608.0f - a.beta;
         asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
         int it = 1;
         bool all_done = false;

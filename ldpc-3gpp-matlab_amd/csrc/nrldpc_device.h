@@ -153,19 +153,30 @@ __device__ __forceinline__ float ingest(float x, float scale, bool core) {
     return y;
 }
 
-// Row minimum m -> message magnitude clamp(rint(alpha*m - beta), 0, 127): one fused multiply-add, then round to
-// nearest even, exactly as scale_mag() of the oracle.  CAPPED: the caller's search started from
-// (127.49 + beta)/alpha, so the upper clamp cannot bind and is left out.
-template <bool CAPPED> __device__ __forceinline__ float scale_mag(const DecArgs& a, float m) {
-    const float x = rintf(__builtin_fmaf(a.alpha, m, -a.beta));
-    if constexpr (CAPPED) return fmaxf(x, 0.0f);
-    else return __builtin_amdgcn_fmed3f(x, 0.0f, 127.0f);
+// Row minimum m -> message magnitude clamp(rint(alpha*m - beta), 0, 127), alpha*m - beta rounded ONCE (nearest, ties to
+// even), as scale_mag() of the oracle: the rounding is done by the fused multiply-add itself.  2^23 - beta is exact
+// because nrldpc_create keeps beta on a grid of half fixed-point units; alpha*m + (2^23 - beta) then rounds at an ulp
+// of 1, i.e. to 2^23 + rint(alpha*m - beta); anything below 2^23 is a negative magnitude and is clamped (m <= 2^20, so
+// the sum stays below 2^24).  v_fma + v_med3 + v_sub.
+__device__ __forceinline__ float scale_mag(const DecArgs& a, float m) {
+    const float y = __builtin_fmaf(a.alpha, m, 8388608.0f - a.beta);
+    return __builtin_amdgcn_fmed3f(y, 8388608.0f, 8388608.0f + 127.0f) - 8388608.0f;
 }
 
 template <int BG> struct DecState {
     uint32_t rm[BGD<BG>::NW];  // check-to-variable messages, int8 x4
     uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4
+    // the same LLRs as floats, for the builds whose register budget has room for them (one v_cvt_f32_i32_sdwa per
+    // extension row and iteration saved); never touched -- so never allocated -- by the others
+    float xf[BGD<BG>::NEXT];
 };
+
+// The same for the software-pipelined builds, with nbeta23 = 2^23 - beta held in a VGPR: v_fma + v_max + v_sub
+// (2.5 + 4 + 2.3 issue cycles; a separate v_rndne would cost 4 more).  The caller's search started from
+// (127.49 + beta)/alpha, so no upper clamp is needed.
+__device__ __forceinline__ float scale_mag_magic(float alpha, float nbeta23, float m) {
+    return fmaxf(__builtin_fmaf(alpha, m, nbeta23), 8388608.0f) - 8388608.0f;
+}
 
 } // namespace nrldpc
 #endif

@@ -203,8 +203,9 @@ int orc_encode(int bg, int Z, const uint8_t* info, int batch, uint8_t* cw) {
 /*            (j < kb+4) -> +/-2^20 (filler "certain" bits, NRLDPCDecoder.m:264)               */
 /*   layer l, row z, edges in ascending column order, v_j = col_j*Z + (z+P_lj) mod Z :         */
 /*            t_j = APP[v_j] - r[l,j,z];  m1<=m2 two smallest |t_j|;  S = xor of (t_j<0)       */
-/*            M1 = clamp(rint(alpha*m1 - beta), 0, 127), M2 likewise with m2 (one fp32 fused          */
-/*            multiply-add, then round to nearest even; beta = 0 is plain normalised min-sum)  */
+/*            M1 = clamp(rint(alpha*m1 - beta), 0, 127), M2 likewise with m2 (exact alpha*m - beta,   */
+/*            rounded once to the nearest integer, ties to even; beta = 0 is plain normalised     */
+/*            min-sum; beta is a multiple of half a grid unit)                                    */
 /*            r'_j = ((t_j<0)^S ? -1 : +1) * (|t_j|==m1 ? M2 : M1);  APP[v_j] = t_j + r'_j     */
 /*   stop     after an iteration if early_term and every parity of the active rows holds        */
 /*   output   hard_k = APP_k < 0 (k < K); app = APP/scale                                      */
@@ -218,10 +219,12 @@ static int32_t ingest(double llr, int scale, int core) {
     return (int32_t)nearbyintf(x);
 }
 
+/* alpha*m - beta is formed exactly (double holds the 24-bit alpha times the <= 21-bit m) and rounded ONCE, to the
+ * nearest integer, ties to even; the kernels get the same value from one fp32 fused multiply-add against 2^23 - beta. */
 static int32_t scale_mag(float alpha, float beta, int32_t m) {
-    float f = nearbyintf(fmaf(alpha, (float)m, -beta));
-    if (f > (float)ORC_QMAX) f = (float)ORC_QMAX;
-    if (f < 0.0f) f = 0.0f;
+    double f = nearbyint((double)alpha * (double)m - (double)beta);
+    if (f > (double)ORC_QMAX) f = (double)ORC_QMAX;
+    if (f < 0.0) f = 0.0;
     return (int32_t)f;
 }
 

@@ -23,8 +23,8 @@ def run_case(pkg, orc, rng, bg, Z, B, esn0, iters, nl=0, et=True, dt=np.float16,
         out = c.decode(llr, want_iters=True, want_app=app)
     finally:
         c.close()
-    if alpha is not None:
-        assert c.alpha == np.float32(alpha) and c.beta == np.float32(beta)
+    if alpha is not None:  # the offset is kept on a grid of half fixed-point units (nrldpc_cfg.beta)
+        assert c.alpha == np.float32(alpha) and c.beta == np.float32(np.rint(2 * np.float32(beta) * scale) / (2 * scale))
     ref = orc.decode_nmsq(bg, Z, llr.astype(np.float64), iters, n_layers=nl, early_term=et, scale=scale, want_app=app,
                           **rule_kw(c, scale))
     assert (out[0] == ref[0]).all(), "hard decisions differ"

@@ -48,9 +48,9 @@ def nmsq_numpy(bg, Z, llr, max_iter, n_layers, early_term, alpha, scale, orc, be
             srt = np.sort(a, axis=0)
             m1, m2 = srt[0], srt[1]
             S = (t < 0).sum(0) & 1
-            # one fused multiply-add in fp32 = the exact product minus beta, rounded once to fp32 (float64 holds
-            # alpha*m - beta exactly: 24-bit alpha x 21-bit m), then round half to even, then clamp to [0, 127]
-            fm = lambda m: np.clip(np.rint((np.float64(np.float32(alpha)) * m - np.float64(np.float32(beta))).astype(np.float32)), 0, 127).astype(np.int64)
+            # alpha*m - beta exactly (float64 holds it: 24-bit alpha x 21-bit m), rounded once to the nearest integer,
+            # ties to even, then clamped to [0, 127]
+            fm = lambda m: np.clip(np.rint(np.float64(np.float32(alpha)) * m - np.float64(np.float32(beta))), 0, 127).astype(np.int64)
             M1, M2 = fm(m1), fm(m2)
             for k, (e, v) in enumerate(zip(es, vidx)):
                 mag = np.where(a[k] == m1, M2, M1)
@@ -73,7 +73,8 @@ def nmsq_numpy(bg, Z, llr, max_iter, n_layers, early_term, alpha, scale, orc, be
 @pytest.mark.parametrize("bg,Z,nl,et,alpha,scale,esn0,beta", [
     (1, 8, 0, False, 0.75, 8, 1.0, 0.0), (1, 24, 10, True, 0.625, 16, 3.0, 0.0), (2, 20, 0, True, 0.75, 8, 0.0, 0.0),
     (2, 6, 6, False, 0.8125, 4, 4.0, 0.0), (1, 36, 46, True, 0.6875, 8, -1.0, 0.0),
-    (1, 36, 46, True, 0.875, 8, -1.0, 3.0), (2, 20, 0, True, 0.8125, 8, 0.0, 2.0), (1, 8, 0, False, 0.7, 16, 1.0, 2.3)])
+    (1, 36, 46, True, 0.875, 8, -1.0, 3.0), (2, 20, 0, True, 0.8125, 8, 0.0, 2.0), (1, 8, 0, False, 0.7, 16, 1.0, 2.5),
+    (2, 20, 0, True, 0.9, 4, 0.0, 1.0), (1, 24, 10, False, 0.3, 8, 2.0, 0.5)])
 def test_nmsq_c_vs_numpy(orc, bg, Z, nl, et, alpha, scale, esn0, beta):
     rng = np.random.default_rng(7)
     kb = BG_DIMS[bg][2]
