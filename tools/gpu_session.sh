@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 1200 python tools/fuzz_decode.py 800 99 2>&1 | tail -1
-python tools/bench_one.py 1 384 4096 0 0 25 2>&1 | grep -v amdgpu
-python tools/bench_one.py 1 96 8192 0 0 25 2>&1 | grep -v amdgpu
-python tools/bench_one.py 2 384 4096 0 30 25 2>&1 | grep -v amdgpu
+bash tools/profile_gpu.sh r02 > gpurun_out/s15_profile.log 2>&1
+python bench.py > gpurun_out/s15_bench.txt 2>gpurun_out/s15_bench.err
+python tools/bench_configs.py > gpurun_out/s15_cfg.txt 2>&1
+python tools/bench_all_z.py > gpurun_out/s15_allz.txt 2>&1
+tail -c 200 gpurun_out/s15_bench.txt
