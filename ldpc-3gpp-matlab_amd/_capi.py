@@ -90,7 +90,11 @@ def load():
     if os.environ.get("NRLDPC_LIB"):
         pass  # an explicitly selected library (kernel experiments): used as it is
     elif _build._stale():  # missing, or built from other sources than the tree holds now (content hash)
-        path = _build.build_lib()
+        import fcntl
+        with open(path + ".lock", "w") as lk:  # several ranks of one node may get here at once: one builds, the rest wait
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if _build._stale():
+                path = _build.build_lib()
     L = C.CDLL(path)
     L.nrldpc_build_id.restype = C.c_char_p
     if not os.environ.get("NRLDPC_LIB") and L.nrldpc_build_id().decode() != _build.source_id():
