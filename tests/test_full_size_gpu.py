@@ -212,3 +212,27 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["value"] > 1.0 and rec["bler"] < 0.05 and "cpu_baseline" not in rec
+
+
+def test_cfg5_full_batch_65536_through_eight_shards(pkg, orc):
+    """BASELINE configs[4] at its full size: 65536 BG1 Z=384 R=8/9 codewords with early termination, cut over EIGHT
+    shards (the pool dispatcher with eight handles and host threads; on this one-GPU box all eight sit on device 0).
+    Size-independent properties: every codeword decoded exactly once and back to its payload (BLER < 2 %), iteration
+    counts in range, a sample equal to the oracle, the work split covers the batch."""
+    rng = np.random.default_rng(65536)
+    bg, Z, B, E = 1, 384, 65536, 9478
+    enc = pkg.Codec(bg, Z, max_iter=1, llr_dtype=np.float16)
+    pool = pkg.CodecPool(bg, Z, [0] * 8, chunks_per_device=3, max_iter=25, n_layers=5, early_term=True, llr_dtype=np.float16)
+    info = rng.integers(0, 2, (B, enc.K), dtype=np.uint8)
+    llr = np.empty((B, enc.N_cw), np.float16)
+    for lo in range(0, B, 8192):                       # chunked: the float noise of the whole batch would be 7 GB
+        llr[lo:lo + 8192] = awgn_llr(rng, enc.encode(info[lo:lo + 8192]), 7.5, np.float16, Z, E=E)
+    hard, it = pool.decode(llr, want_iters=True)
+    split = pool.last_split()
+    pool.close(); enc.close()
+    assert sum(split) == B and len(split) == 8 and min(split) > 0
+    assert (hard != info).any(1).mean() < 0.02 and it.min() >= 1 and it.max() <= 25 and it.mean() < 8
+    a, b = pkg.default_rule(bg, 5)
+    sample = rng.choice(B, 6, replace=False)
+    ho, io = orc.decode_nmsq(bg, Z, llr[sample].astype(np.float64), 25, n_layers=5, early_term=True, alpha=a, beta=b * 8)
+    assert (hard[sample] == ho).all() and (it[sample] == io).all()
