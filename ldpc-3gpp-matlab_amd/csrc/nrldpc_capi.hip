@@ -219,6 +219,11 @@ struct nrldpc_codec {
     static constexpr int kMultiSlots = 4;
     MultiSlot multi[kMultiSlots];
     int multi_next = 0;
+    // side streams for the launches of one nrldpc_decode_multi_dev call: each launch is bound by its slowest
+    // workgroups (25 iterations of a codeword that never converges), not by throughput, so the launches of the two
+    // base graphs overlap almost perfectly (fork / join with events around the caller's stream)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // pipelined host path (large batches): two pinned slots, two streams, copy threads
     PinBuf pin_in[2], pin_out[2], pin_it[2];
     hipStream_t xs[2] = {nullptr, nullptr};
@@ -448,6 +453,11 @@ void nrldpc_destroy(nrldpc_handle h) {
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
     h->s_llr.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
+    for (int i = 0; i < 3; ++i) {
+        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int i = 0; i < 2; ++i) {
@@ -510,22 +520,24 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     nrldpc_codec* own = hs[0]; // its scratch holds the tables
     DEVICE_SCOPE(own);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // A configuration whose (BG, Z) has a compile-time-Z kernel and whose batch fills the chip at least once goes to
-    // that kernel in a launch of its own (0.55-0.7x the time per codeword); everything else shares ONE launch of the
-    // run-time-Z kernel per (base graph, LLR type): argument blocks, then the workgroup prefix table.
+    // A configuration whose (BG, Z) has a compile-time-Z kernel (0.55-0.7x the time per codeword) and at least
+    // NRLDPC_MULTI_Z64_MIN_ROWS check rows of work (default 512*384: it fills the chip; measured on BASELINE config 4,
+    // whose buckets hold ~80 codewords: own launches from 16*384 / 64*384 / 256*384 rows on take 1.47 / 0.89 / 0.58 ms
+    // against 0.57 ms with none) gets a launch of its own on that kernel; everything else shares ONE
+    // launch of the run-time-Z kernel per (base graph, LLR type): argument blocks, then the workgroup prefix table.
+    // All launches of the call are spread over the caller's stream and three side streams (fork / join with events):
+    // a bucket's own launch fills only part of the chip, and the shared launches end in a tail of codewords that
+    // never converge.
     static const long env_rows = getenv("NRLDPC_MULTI_Z64_MIN_ROWS") ? atol(getenv("NRLDPC_MULTI_Z64_MIN_ROWS")) : 512L * 384L;
+    static const bool one_stream = getenv("NRLDPC_MULTI_ONE_STREAM") != nullptr; // A/B
     struct Group { std::vector<nrldpc::DecArgs> args; std::vector<int32_t> start; size_t lds = 0; int grid = 0; };
     Group g[2][2];
+    std::vector<int> routed;
     for (int i = 0; i < n; ++i) {
         if (batch[i] == 0) continue;
         nrldpc_codec* h = hs[i];
         const nrldpc::Schedule& s = h->sched;
-        if ((long)batch[i] * s.Z >= env_rows && nrldpc::has_z64_kernel(s.g.bg, s.Z)) {
-            const nrldpc::DecArgs a = make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr);
-            hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, st);
-            if (e != hipSuccess) return hipfail(e, "decode kernel launch");
-            continue;
-        }
+        if ((long)batch[i] * s.Z >= env_rows && nrldpc::has_z64_kernel(s.g.bg, s.Z)) { routed.push_back(i); continue; }
         Group& q = g[s.g.bg - 1][h->cfg.llr_dtype == NRLDPC_LLR_F16 ? 1 : 0];
         q.args.push_back(make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr));
         q.start.push_back(q.grid);
@@ -534,10 +546,12 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     }
     std::vector<char> host;
     size_t off[2][2][2];
+    int nlaunch = (int)routed.size();
     for (int b = 0; b < 2; ++b)
         for (int d = 0; d < 2; ++d) {
             Group& q = g[b][d];
             if (q.args.empty()) continue;
+            ++nlaunch;
             q.start.push_back(q.grid);
             host.resize((host.size() + 15) & ~(size_t)15);
             off[b][d][0] = host.size();
@@ -547,25 +561,51 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
             host.insert(host.end(), reinterpret_cast<const char*>(q.start.data()),
                         reinterpret_cast<const char*>(q.start.data() + q.start.size()));
         }
-    if (host.empty()) return NRLDPC_OK;
+    if (nlaunch == 0) return NRLDPC_OK;
     // table slot: reused only after the launches that read it have completed (calls on different streams may overlap)
     nrldpc_codec::MultiSlot& m = own->multi[own->multi_next];
     own->multi_next = (own->multi_next + 1) % nrldpc_codec::kMultiSlots;
     if (!m.done) HIP_TRY(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
     if (m.used) HIP_TRY(hipEventSynchronize(m.done));
-    HIP_TRY(m.pin.reserve(host.size()));
-    HIP_TRY(m.dev.reserve(host.size()));
-    memcpy(m.pin.p, host.data(), host.size());
-    HIP_TRY(hipMemcpyAsync(m.dev.p, m.pin.p, host.size(), hipMemcpyHostToDevice, st));
-    int rc = NRLDPC_OK;
+    if (!host.empty()) {
+        HIP_TRY(m.pin.reserve(host.size()));
+        HIP_TRY(m.dev.reserve(host.size()));
+        memcpy(m.pin.p, host.data(), host.size());
+        HIP_TRY(hipMemcpyAsync(m.dev.p, m.pin.p, host.size(), hipMemcpyHostToDevice, st));
+    }
+    const bool fan = nlaunch > 1 && !one_stream;
+    if (fan) { // fork: the side streams start after the table copy (and everything the caller queued before it)
+        if (!own->ev_fork) HIP_TRY(hipEventCreateWithFlags(&own->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(own->ev_fork, st));
+        for (int i = 0; i < 3; ++i) {
+            if (!own->side[i]) HIP_TRY(hipStreamCreateWithFlags(&own->side[i], hipStreamNonBlocking));
+            if (!own->ev_join[i]) HIP_TRY(hipEventCreateWithFlags(&own->ev_join[i], hipEventDisableTiming));
+            HIP_TRY(hipStreamWaitEvent(own->side[i], own->ev_fork, 0));
+        }
+    }
+    int rc = NRLDPC_OK, k = 0;
+    auto next_stream = [&]() -> hipStream_t { const int q = k++ & 3; return (!fan || q == 0) ? st : own->side[q - 1]; };
+    // shared launches first (the longest: their tail of never-converging small codewords), then the buckets' own
     for (int b = 0; b < 2 && rc == NRLDPC_OK; ++b)
         for (int d = 0; d < 2 && rc == NRLDPC_OK; ++d) {
             const Group& q = g[b][d];
             if (q.args.empty()) continue;
             hipError_t e = nrldpc::launch_decode_multi(
                 b + 1, d ? NRLDPC_K_F16 : NRLDPC_K_F32, reinterpret_cast<const nrldpc::DecArgs*>(m.dev.p + off[b][d][0]),
-                reinterpret_cast<const int32_t*>(m.dev.p + off[b][d][1]), (int)q.args.size(), q.grid, q.lds, st);
+                reinterpret_cast<const int32_t*>(m.dev.p + off[b][d][1]), (int)q.args.size(), q.grid, q.lds, next_stream());
             if (e != hipSuccess) rc = hipfail(e, "multi-configuration decode launch");
+        }
+    for (size_t r = 0; r < routed.size() && rc == NRLDPC_OK; ++r) {
+        const int i = routed[r];
+        nrldpc_codec* h = hs[i];
+        const nrldpc::DecArgs a = make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr);
+        hipError_t e = nrldpc::launch_decode(h->sched.g.bg, a, h->sched.threads, h->sched.lds_bytes, next_stream());
+        if (e != hipSuccess) rc = hipfail(e, "decode kernel launch");
+    }
+    if (fan)
+        for (int i = 0; i < 3; ++i) { // join: the caller's stream continues after every side launch
+            (void)hipEventRecord(own->ev_join[i], own->side[i]);
+            (void)hipStreamWaitEvent(st, own->ev_join[i], 0);
         }
     (void)hipEventRecord(m.done, st); // also on a failed launch: the copy above is in flight
     m.used = true;
