@@ -64,6 +64,25 @@ def _profile():
     return None, {}, {}
 
 
+def bler_match():
+    """Second half of the metric ('BLER match vs MATLAB ref'): the dB gap to flooding sum-product (the reference's
+    semantics) at equal iteration caps, measured by tests/test_bler_gap_gpu.py on identical noise and committed under
+    profiles/ -- the headline configuration's entry, plus the worst gap over all BASELINE configurations."""
+    for tag in PROFILE_TAGS:
+        p = os.path.join(ROOT, "profiles", tag + "_bler_gap.json")
+        if os.path.exists(p):
+            try:
+                d = json.load(open(p))
+                head = next(v for k, v in d.items() if "headline" in k)
+                return {"headline_gap_dB": head["gap_dB"], "EsN0_at_bler_0.1_gpu": head["EsN0_at_bler_0.1_gpu"],
+                        "EsN0_at_bler_0.1_sum_product": head["EsN0_at_bler_0.1_sum_product"], "blocks": head["blocks"],
+                        "worst_gap_dB_all_configs": max(v["gap_dB"] for v in d.values()), "bound_dB": head["bound_dB"],
+                        "source": "profiles/%s_bler_gap.json (tests/test_bler_gap_gpu.py)" % tag}
+            except Exception:
+                pass
+    return None
+
+
 def synth_llr(torch, codec, batch, seed, dev):
     """Random payloads -> GPU encoder -> QPSK/AWGN LLRs, fp16, first 2Z columns punctured (=0)."""
     g = torch.Generator(device=dev)
@@ -305,6 +324,7 @@ def main():
                                  "VALU issue does (secondary)" % (N_CW * 2 + K),
                          "secondary": secondary},
             "bler": bler,
+            "bler_match": bler_match(),
         }
         if world == 1:  # CPU baseline and host-path legs at N = 1 only
             if args.cpu_sample > 0:
