@@ -132,9 +132,10 @@ def test_cfg4_mixed_batch_in_one_call_matches_the_oracle(pkg, orc):
     for k, ((bg, Z), n) in enumerate(sorted(buckets.items())):
         rows, cols, kb = BG_DIMS[bg]
         nl = 0 if k % 3 else max(4, rows - (k % 11))               # some pruned layer counts
-        c = pkg.Codec(bg, Z, max_iter=8 + (k % 5), n_layers=nl, early_term=bool(k % 4), llr_dtype=np.float16)
+        dt = np.float16 if k % 3 else np.float32                   # both LLR types in one call: four launch groups
+        c = pkg.Codec(bg, Z, max_iter=8 + (k % 5), n_layers=nl, early_term=bool(k % 4), llr_dtype=dt)
         info = rng.integers(0, 2, (n, kb * Z), dtype=np.uint8)
-        x = awgn_llr(rng, c.encode(info), 2.0, np.float16, Z)
+        x = awgn_llr(rng, c.encode(info), 2.0, dt, Z)
         llr = torch.from_numpy(x).cuda()
         h = torch.empty((n, kb * Z), dtype=torch.uint8, device="cuda")
         it = torch.empty(n, dtype=torch.int32, device="cuda")
