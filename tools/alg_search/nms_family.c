@@ -4,6 +4,9 @@
  * decoder closest to flooding sum-product (the reference's semantics, NRLDPCDecoder.m:120) at equal
  * iteration caps.  tools/alg_search/search.py drives it; the winner is then restated in oracle/ and csrc/.
  *
+ * Build:  gcc -O3 -march=native -fopenmp -fPIC -shared -o tools/alg_search/libnmsf.so tools/alg_search/nms_family.c -lm
+ * Run:    python tools/alg_search/bpref.py headline 1024 ; python tools/alg_search/search.py headline 512 '[{"alpha":0.875,"beta":3}]'
+ *
  *   per row:  m1 <= m2 two smallest |t_j|
  *             a1 = max(0, m1 - max(0, c0 - c1*(m2 - m1)))      two-min (box-plus) correction of the smallest
  *             M1 = clamp(rint(alpha[l]*a1) - beta, 0, msg_max)  sent to every edge but the arg-min
