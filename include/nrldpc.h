@@ -45,7 +45,8 @@ extern "C" {
  * 0 = punctured / untransmitted, +inf = filler bit (known 0). */
 #define NRLDPC_LLR_F32 0
 #define NRLDPC_LLR_F16 1
-#define NRLDPC_LLR_F64 2 /* host entry point only (MATLAB double); narrowed to f32 on the host */
+#define NRLDPC_LLR_F64 2 /* host entry point only (MATLAB double); narrowed to f32 -- large batches: quantised to the
+                            kernels' int8 grid, see nrldpc_quantise_llr -- on the host */
 
 typedef struct nrldpc_codec* nrldpc_handle;
 
@@ -86,6 +87,13 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
                   float* app_out);
 int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t* d_hard,
                       int32_t* d_iters_out, float* d_app_out, void* stream);
+
+/* The quantisation nrldpc_decode applies to large host batches while it copies them into its pinned staging
+ * buffers (so that 1 byte per LLR crosses PCIe instead of 4): dst[i] = NaN ? 0 : rint(clamp(float(src[i]) * llr_scale,
+ * +-127)) as int8 -- the kernels' own ingest arithmetic, operation for operation -- with +inf (filler bits,
+ * NRLDPCDecoder.m:264) as -128.  src: n values of llr_dtype (NRLDPC_LLR_*).  Returns 1 when a -inf was met (int8 has
+ * no code for it; nrldpc_decode then sends that chunk in its own format), else 0.  Host function, no device needed. */
+int nrldpc_quantise_llr(int8_t* dst, const void* src, int64_t n, int32_t llr_dtype, int32_t llr_scale);
 
 /* Mixed batches: n configurations (handles of one device that may differ in base graph, lifting size, layer
  * count, iteration cap, ...) decoded with one launch per base graph and LLR type instead of n launches --

@@ -58,7 +58,7 @@ def tb_params(p):
 
 
 EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_check_harq_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
-           "nrldpc_decode_multi_dev", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
+           "nrldpc_decode_multi_dev", "nrldpc_quantise_llr", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version", "nrldpc_build_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
            "nrldpc_pool_destroy"]
@@ -107,6 +107,7 @@ def load():
     L.nrldpc_get_dims.argtypes = [vp, C.POINTER(Dims)]
     L.nrldpc_decode.argtypes = [vp, vp, i32, vp, vp, vp]
     L.nrldpc_decode_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.nrldpc_quantise_llr.argtypes = [vp, vp, C.c_int64, i32, i32]
     L.nrldpc_decode_multi_dev.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), vp]
     L.nrldpc_encode.argtypes = [vp, vp, i32, vp]
     L.nrldpc_encode_dev.argtypes = [vp, vp, i32, vp, vp]
@@ -329,6 +330,15 @@ def crc_attach_dev(p, d_a, n_tb, d_c, stream=0):
 def rate_match_dev(p, d_cw, n_tb, d_g, stream=0):
     t = p if isinstance(p, TbParams) else tb_params(p)
     check(load().nrldpc_rate_match_dev(C.byref(t), _ptr(d_cw), int(n_tb), _ptr(d_g), C.c_void_p(stream)))
+
+
+def quantise_llr(llr, llr_scale=8):
+    """The int8 form nrldpc_decode puts on the wire for large host batches (include/nrldpc.h): (q, saw_negative_infinity)."""
+    llr = np.ascontiguousarray(llr)
+    kind = {np.dtype(np.float32): LLR_F32, np.dtype(np.float16): LLR_F16, np.dtype(np.float64): LLR_F64}[llr.dtype]
+    q = np.empty(llr.shape, np.int8)
+    neg = load().nrldpc_quantise_llr(_ptr(q), _ptr(llr), llr.size, kind, int(llr_scale))
+    return q, bool(neg)
 
 
 def default_rule(bg, n_layers=0):

@@ -15,7 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip.so")  # env override: kernel experiments
 OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_channel.hip",
-           "nrldpc_capi.hip"]
+           "nrldpc_capi.hip", "nrldpc_host_quant.cpp"]  # .cpp: host-only C++ (no device pass)
 Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
 # = NRLDPC_Z64_LIST (nrldpc_kernels.h): the sizes where the compile-time-Z kernel beats the run-time-Z one
 Z64_BG1 = (60, 64, 104, 112, 120, 128, 144, 176, 192, 208, 224, 240, 256, 288, 320, 352, 384)
@@ -23,7 +23,7 @@ Z64_BG2 = (52, 60, 64, 88, 96, 104, 112, 120, 128, 144, 192, 208, 224, 240, 256,
 Z64_PAIRS = [(1, z) for z in Z64_BG1] + [(2, z) for z in Z64_BG2]
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7)]
-HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_wave.h"]
+HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_wave.h", "nrldpc_host_quant.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -70,7 +70,7 @@ def build_lib(force=False, verbose=False, jobs=None):
     sid = source_id()
     os.makedirs(OBJDIR, exist_ok=True)
     inc = ["-I" + INCLUDE, "-I" + CSRC]
-    units = [(os.path.join(CSRC, f), os.path.join(OBJDIR, f.replace(".hip", ".o")),
+    units = [(os.path.join(CSRC, f), os.path.join(OBJDIR, os.path.splitext(f)[0] + ".o"),
               ['-DNRLDPC_BUILD_ID="%s"' % sid] if f == "nrldpc_capi.hip" else []) for f in SOURCES]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d.o" % (bg, z)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64_PAIRS]
@@ -82,7 +82,8 @@ def build_lib(force=False, verbose=False, jobs=None):
         src, obj, defs = u
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest and not src.endswith("nrldpc_capi.hip"):
             return obj
-        cmd = [hipcc, *FLAGS, *inc, *defs, "-c", src, "-o", obj]
+        flags = [f for f in FLAGS if not f.startswith("--offload-arch")] if src.endswith(".cpp") else FLAGS
+        cmd = [hipcc, *flags, *inc, *defs, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +24,7 @@
 
 #include "nrldpc.h"
 #include "nrldpc_kernels.h"
+#include "nrldpc_host_quant.h"
 #include "nrldpc_sched.h"
 
 namespace {
@@ -128,13 +131,24 @@ static bool caller_node_cpus(cpu_set_t* out) {
 }
 
 class HostPool {
+    // Fork/join on every chunk of a pipelined call: a dozen jobs of 0.1-0.4 ms each within a few milliseconds.  Waking
+    // sixteen sleeping threads through a condition variable costs 0.15-0.2 ms per job (measured: 13 chunks x 2 jobs made
+    // 4 ms of a 12 ms call), so workers poll the generation counter for a short while after a job before they go back
+    // to sleep, and the caller polls the completion counter.
     std::vector<std::thread> th_;
     std::mutex m_;
-    std::condition_variable cv_, cv_done_;
+    std::condition_variable cv_;
     std::function<void(int, int)> job_;
-    unsigned gen_ = 0;
-    int pending_ = 0;
-    bool stop_ = false;
+    std::atomic<unsigned> gen_{0};
+    std::atomic<int> pending_{0};
+    std::atomic<int> sleepers_{0};
+    std::atomic<bool> stop_{false};
+
+    static void relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 
 public:
     explicit HostPool(int n) {
@@ -145,38 +159,53 @@ public:
                 if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof node, &node);
                 unsigned seen = 0;
                 for (;;) {
-                    std::function<void(int, int)> f;
-                    {
-                        std::unique_lock<std::mutex> lk(m_);
-                        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-                        if (stop_) return;
-                        seen = gen_;
-                        f = job_;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    int polls = 0;
+                    while (gen_.load(std::memory_order_acquire) == seen && !stop_.load(std::memory_order_relaxed)) {
+                        relax();
+                        if ((++polls & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) {
+                            std::unique_lock<std::mutex> lk(m_);
+                            sleepers_.fetch_add(1);
+                            cv_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
+                            sleepers_.fetch_sub(1);
+                        }
                     }
-                    f(i, n);
-                    {
-                        std::lock_guard<std::mutex> lk(m_);
-                        if (--pending_ == 0) cv_done_.notify_all();
-                    }
+                    if (stop_.load()) return;
+                    seen = gen_.load(std::memory_order_acquire);
+                    job_(i, n); // published before the generation moved; the next run() starts only after this one is done
+                    pending_.fetch_sub(1, std::memory_order_acq_rel);
                 }
             });
     }
     ~HostPool() {
         {
             std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
+            stop_.store(true);
         }
         cv_.notify_all();
         for (auto& t : th_) t.join();
     }
     // f(worker, nworkers) on every worker; returns when all are done
     void run(std::function<void(int, int)> f) {
-        std::unique_lock<std::mutex> lk(m_);
         job_ = std::move(f);
-        pending_ = (int)th_.size();
-        ++gen_;
-        cv_.notify_all();
-        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        pending_.store((int)th_.size(), std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(m_); // a worker between its last poll and cv_.wait holds this lock
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        if (sleepers_.load() > 0) cv_.notify_all();
+        while (pending_.load(std::memory_order_acquire) != 0) relax();
+    }
+    // dst[i] = int8 grid value of src[i] (nrldpc_host_quant.h) for n elements; true when a -inf was met
+    bool quantise(int8_t* dst, const void* src, size_t n, int kind, float scale) {
+        std::atomic<int> neg{0};
+        const size_t es = kind == NRLDPC_HQ_F64 ? 8 : kind == NRLDPC_HQ_F16 ? 2 : 4;
+        run([=, &neg](int w, int nw) {
+            const size_t per = ((n + nw - 1) / nw + 63) & ~(size_t)63, lo = std::min(n, per * w), hi = std::min(n, lo + per);
+            if (hi > lo && nrldpc_quantise_i8(dst + lo, static_cast<const char*>(src) + lo * es, hi - lo, kind, scale))
+                neg.store(1, std::memory_order_relaxed);
+        });
+        return neg.load() != 0;
     }
     // dst[i] = src[i] for n bytes, or float(dst) = double(src) for n elements when narrow
     void move(void* dst, const void* src, size_t n, bool narrow) {
@@ -225,9 +254,10 @@ struct nrldpc_codec {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // pipelined host path (large batches): two pinned slots, two streams, copy threads
-    PinBuf pin_in[2], pin_out[2], pin_it[2];
+    static constexpr int kSlots = 4; // chunks the host may run ahead of the device
+    PinBuf pin_in[kSlots], pin_out[kSlots], pin_it[kSlots];
     hipStream_t xs[2] = {nullptr, nullptr};
-    hipEvent_t xdone[2] = {nullptr, nullptr};
+    hipEvent_t xdone[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     HostPool* pool = nullptr;
     // timing
     bool timing = false, have_time = false;
@@ -293,7 +323,7 @@ void end_timing(nrldpc_codec* h, hipStream_t s) {
 }
 
 nrldpc::DecArgs make_dec_args(const nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters,
-                              float* d_app) {
+                              float* d_app, int llr_kind = -1) {
     const nrldpc::Schedule& s = h->sched;
     nrldpc::DecArgs a;
     memset(&a, 0, sizeof a);
@@ -302,16 +332,16 @@ nrldpc::DecArgs make_dec_args(const nrldpc_codec* h, const void* d_llr, int batc
     a.batch = batch; a.Z = s.Z; a.n_layers = s.n_layers; a.max_iter = h->cfg.max_iter; a.ncw = s.ncw; a.sbw = s.sbw;
     a.early_term = h->cfg.early_term ? 1 : 0;
     a.need_ext = (a.early_term || d_app) ? 1 : 0;
-    a.llr_kind = (h->cfg.llr_dtype == NRLDPC_LLR_F16) ? NRLDPC_K_F16 : NRLDPC_K_F32;
+    a.llr_kind = llr_kind >= 0 ? llr_kind : (h->cfg.llr_dtype == NRLDPC_LLR_F16) ? NRLDPC_K_F16 : NRLDPC_K_F32;
     a.alpha = h->alpha; a.scale = (float)h->scale; a.inv_scale = 1.0f / (float)h->scale;
     a.beta = h->beta * (float)h->scale;
     return a;
 }
 
 int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters, float* d_app,
-                  hipStream_t stream) {
+                  hipStream_t stream, int llr_kind = -1) {
     const nrldpc::Schedule& s = h->sched;
-    const nrldpc::DecArgs a = make_dec_args(h, d_llr, batch, d_hard, d_iters, d_app);
+    const nrldpc::DecArgs a = make_dec_args(h, d_llr, batch, d_hard, d_iters, d_app, llr_kind);
     begin_timing(h, stream);
     hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, stream);
     end_timing(h, stream);
@@ -460,11 +490,12 @@ void nrldpc_destroy(nrldpc_handle h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < nrldpc_codec::kSlots; ++i) {
         h->pin_in[i].release(); h->pin_out[i].release(); h->pin_it[i].release();
-        if (h->xs[i]) (void)hipStreamDestroy(h->xs[i]);
         if (h->xdone[i]) (void)hipEventDestroy(h->xdone[i]);
     }
+    for (int i = 0; i < 2; ++i)
+        if (h->xs[i]) (void)hipStreamDestroy(h->xs[i]);
     delete h->pool;
     delete h;
 }
@@ -613,6 +644,12 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     NRLDPC_API_END
 }
 
+int nrldpc_quantise_llr(int8_t* dst, const void* src, int64_t n, int32_t llr_dtype, int32_t llr_scale) {
+    if (n <= 0 || !dst || !src) return 0;
+    const int kind = llr_dtype == NRLDPC_LLR_F64 ? NRLDPC_HQ_F64 : llr_dtype == NRLDPC_LLR_F16 ? NRLDPC_HQ_F16 : NRLDPC_HQ_F32;
+    return nrldpc_quantise_i8(dst, src, (size_t)n, kind, (float)llr_scale) ? 1 : 0;
+}
+
 int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out) {
     NRLDPC_API_BEGIN
     if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
@@ -630,58 +667,97 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     if (iters_out) HIP_TRY(h->s_iters.reserve(cap));
     if (app_out) HIP_TRY(h->s_app.reserve(cap * ncw));
 
-    // Batches above 8 MB: chunks of up to ~32 MB (NRLDPC_HOST_CHUNK_MB; NRLDPC_HOST_THREADS copy threads, default 8, pinned to the
-    // caller's NUMA node unless NRLDPC_HOST_NO_PIN is set;
-    // NRLDPC_HOST_PIPELINE=0 disables) flow caller array -> pinned slot (copy threads) -> H2D -> decode -> D2H ->
-    // pinned slot -> caller array on two alternating streams, so that host copies, both DMA directions and
-    // the kernels of neighbouring chunks overlap.  Same kernels, same results as one launch.
+    // Batches above 8 MB: chunks (NRLDPC_HOST_CHUNK_MB of wire bytes, default 32 / 16 as int8; NRLDPC_HOST_THREADS copy threads,
+    // default 16, pinned to the caller's NUMA node unless NRLDPC_HOST_NO_PIN is set; NRLDPC_HOST_PIPELINE=0 disables)
+    // flow caller array -> pinned slot (copy threads; quantised to int8 on the way when the kernel reads that) -> H2D ->
+    // decode -> D2H -> pinned slot -> caller array through four slots on two alternating streams, so that host copies,
+    // both DMA directions and the kernels of neighbouring chunks overlap and the host runs up to three chunks ahead of
+    // the device.  Same results as one launch (NRLDPC_HOST_TRACE=1: phase times of each call on stderr).
     const size_t in_bytes = (size_t)batch * ncw * eb;
     static const int env_chunk_mb = getenv("NRLDPC_HOST_CHUNK_MB") ? atoi(getenv("NRLDPC_HOST_CHUNK_MB")) : 32;
-    static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 8;
+    static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 16;
+    // The copy threads quantise while they copy (1 byte per LLR on the wire instead of 2 / 4; nrldpc_host_quant.h): the
+    // kernels that read the int8 format are the compile-time-Z ones.  NRLDPC_HOST_I8=0: A/B against the native format.
+    const bool i8 = nrldpc::has_z64_kernel(s.g.bg, s.Z) && !(getenv("NRLDPC_HOST_I8") && atoi(getenv("NRLDPC_HOST_I8")) == 0);
+    const int hq_kind = f64 ? NRLDPC_HQ_F64 : h->cfg.llr_dtype == NRLDPC_LLR_F16 ? NRLDPC_HQ_F16 : NRLDPC_HQ_F32;
+    const size_t host_eb = f64 ? 8 : eb; // element size of the caller's array
     static const int env_pipe = getenv("NRLDPC_HOST_PIPELINE") ? atoi(getenv("NRLDPC_HOST_PIPELINE")) : 1;
     if (env_pipe && in_bytes >= ((size_t)8 << 20) && !app_out && !h->timing) {
-        const size_t chunk_bytes = std::min<size_t>((size_t)std::max(1, env_chunk_mb) << 20, in_bytes / 4); // >= 4 chunks
-        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, chunk_bytes / (ncw * eb)));
+        constexpr int NS = nrldpc_codec::kSlots;
+        // chunk: ~NRLDPC_HOST_CHUNK_MB of wire bytes (int8 when the copy threads quantise), at least four chunks per call,
+        // and -- where that leaves more than one -- whole rounds of 512 codewords (two per CU of a 256-CU device: a
+        // 642-codeword chunk ran as one full round and a quarter-full one)
+        const size_t wire_eb = i8 ? 1 : eb;
+        const size_t chunk_bytes = std::min<size_t>(((size_t)std::max(1, env_chunk_mb) << 20) / (i8 ? 2 : 1), (size_t)batch * ncw * wire_eb / 4);
+        int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, chunk_bytes / (ncw * wire_eb)));
+        if (chunk >= 512) chunk -= chunk % 512;
         if (!h->pool) {
             const unsigned hc = std::thread::hardware_concurrency();
             h->pool = new (std::nothrow) HostPool((int)std::max(1u, std::min((unsigned)std::max(1, env_threads), hc ? hc / 2 : 4u)));
             if (!h->pool) return fail(NRLDPC_ERR_NOMEM, "host thread pool");
         }
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NS; ++i) {
             HIP_TRY(h->pin_in[i].reserve((size_t)chunk * ncw * eb));
             HIP_TRY(h->pin_out[i].reserve((size_t)chunk * K));
             if (iters_out) HIP_TRY(h->pin_it[i].reserve((size_t)chunk * 4));
-            if (!h->xs[i]) HIP_TRY(hipStreamCreateWithFlags(&h->xs[i], hipStreamNonBlocking));
             if (!h->xdone[i]) HIP_TRY(hipEventCreateWithFlags(&h->xdone[i], hipEventDisableTiming));
         }
+        for (int i = 0; i < 2; ++i)
+            if (!h->xs[i]) HIP_TRY(hipStreamCreateWithFlags(&h->xs[i], hipStreamNonBlocking));
         const int nchunks = (batch + chunk - 1) / chunk;
         // an early error return must not leave copies or kernels of this call in flight on the two streams
         struct Quiesce {
             hipStream_t* xs; bool armed = true;
             ~Quiesce() { if (armed) for (int i = 0; i < 2; ++i) if (xs[i]) (void)hipStreamSynchronize(xs[i]); }
         } quiesce{h->xs};
+        static const bool trace = getenv("NRLDPC_HOST_TRACE") != nullptr; // phase times of one call on stderr
+        double t_quant = 0, t_wait = 0, t_out = 0, t_enq = 0;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        int drained = 0; // chunks 0 .. drained-1 are back in the caller's arrays
         auto drain = [&](int k) -> int { // results of chunk k: pinned slot -> caller arrays
-            const int sl = k & 1, c0 = k * chunk, n = std::min(chunk, batch - c0);
+            const int sl = k % NS, c0 = k * chunk, n = std::min(chunk, batch - c0);
+            const double t0 = now();
             HIP_TRY(hipEventSynchronize(h->xdone[sl]));
+            const double t1 = now();
             h->pool->move(hard + (size_t)c0 * K, h->pin_out[sl].p, (size_t)n * K, false);
+            t_wait += t1 - t0; t_out += now() - t1;
             if (iters_out) memcpy(iters_out + c0, h->pin_it[sl].p, (size_t)n * 4);
             return NRLDPC_OK;
         };
         for (int k = 0; k < nchunks; ++k) {
-            const int sl = k & 1, c0 = k * chunk, n = std::min(chunk, batch - c0);
-            if (k >= 2) { int rc = drain(k - 2); if (rc) return rc; } // also frees pin_in[sl]
+            const int sl = k % NS, st = k & 1, c0 = k * chunk, n = std::min(chunk, batch - c0);
+            // the slot's previous chunk has to be out (that also frees pin_in[sl]); chunks that happen to be finished
+            // are taken out now rather than in one lump at the end
+            while (drained <= k - NS || (drained < k && hipEventQuery(h->xdone[drained % NS]) == hipSuccess)) {
+                int rc = drain(drained); if (rc) return rc;
+                ++drained;
+            }
             const size_t off = (size_t)c0 * ncw;
-            if (f64) h->pool->move(h->pin_in[sl].p, static_cast<const double*>(llr) + off, (size_t)n * ncw, true);
-            else h->pool->move(h->pin_in[sl].p, static_cast<const char*>(llr) + off * eb, (size_t)n * ncw * eb, false);
             char* d_in = h->s_llr.p + off * eb;
-            HIP_TRY(hipMemcpyAsync(d_in, h->pin_in[sl].p, (size_t)n * ncw * eb, hipMemcpyHostToDevice, h->xs[sl]));
-            int rc = decode_launch(h, d_in, n, h->s_hard.p + (size_t)c0 * K, iters_out ? h->s_iters.p + c0 : nullptr, nullptr, h->xs[sl]);
+            int kind = -1; // the handle's own format
+            const double tq0 = now();
+            if (i8 && !h->pool->quantise(reinterpret_cast<int8_t*>(h->pin_in[sl].p), static_cast<const char*>(llr) + off * host_eb,
+                                         (size_t)n * ncw, hq_kind, (float)h->scale)) {
+                kind = NRLDPC_K_I8;
+                HIP_TRY(hipMemcpyAsync(d_in, h->pin_in[sl].p, (size_t)n * ncw, hipMemcpyHostToDevice, h->xs[st]));
+            } else { // (a chunk that holds a -inf has no int8 form)
+                if (f64) h->pool->move(h->pin_in[sl].p, static_cast<const double*>(llr) + off, (size_t)n * ncw, true);
+                else h->pool->move(h->pin_in[sl].p, static_cast<const char*>(llr) + off * eb, (size_t)n * ncw * eb, false);
+                HIP_TRY(hipMemcpyAsync(d_in, h->pin_in[sl].p, (size_t)n * ncw * eb, hipMemcpyHostToDevice, h->xs[st]));
+            }
+            const double tq1 = now();
+            int rc = decode_launch(h, d_in, n, h->s_hard.p + (size_t)c0 * K, iters_out ? h->s_iters.p + c0 : nullptr, nullptr, h->xs[st], kind);
             if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(h->pin_out[sl].p, h->s_hard.p + (size_t)c0 * K, (size_t)n * K, hipMemcpyDeviceToHost, h->xs[sl]));
-            if (iters_out) HIP_TRY(hipMemcpyAsync(h->pin_it[sl].p, h->s_iters.p + c0, (size_t)n * 4, hipMemcpyDeviceToHost, h->xs[sl]));
-            HIP_TRY(hipEventRecord(h->xdone[sl], h->xs[sl]));
+            t_quant += tq1 - tq0; t_enq -= tq1;
+            HIP_TRY(hipMemcpyAsync(h->pin_out[sl].p, h->s_hard.p + (size_t)c0 * K, (size_t)n * K, hipMemcpyDeviceToHost, h->xs[st]));
+            if (iters_out) HIP_TRY(hipMemcpyAsync(h->pin_it[sl].p, h->s_iters.p + c0, (size_t)n * 4, hipMemcpyDeviceToHost, h->xs[st]));
+            HIP_TRY(hipEventRecord(h->xdone[sl], h->xs[st]));
+            t_enq += now();
         }
-        for (int k = std::max(0, nchunks - 2); k < nchunks; ++k) { int rc = drain(k); if (rc) return rc; }
+        for (; drained < nchunks; ++drained) { int rc = drain(drained); if (rc) return rc; }
+        if (trace)
+            fprintf(stderr, "[nrldpc host path] %d chunks of %d: copy/quantise in %.2f ms (incl. H2D enqueue), launch+D2H enqueue %.2f, wait for device %.2f, copy out %.2f\n",
+                    nchunks, chunk, t_quant, t_enq, t_wait, t_out);
         quiesce.armed = false; // every chunk was drained behind its event
         return NRLDPC_OK;
     }

@@ -1,0 +1,18 @@
+// nrldpc_host_quant.h -- host-side LLR quantisation for the host-pointer decode path (plain C++, no HIP).
+#ifndef NRLDPC_HOST_QUANT_H
+#define NRLDPC_HOST_QUANT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#define NRLDPC_HQ_F32 0
+#define NRLDPC_HQ_F16 1
+#define NRLDPC_HQ_F64 2
+
+// dst[i] = the decoder kernels' ingest() of src[i] as int8: NaN ? 0 : rint(clamp(float(src[i]) * scale, +-127)), +inf as
+// -128 (the kernel knows whether the position is a core column, where +inf means a filler bit, NRLDPCDecoder.m:264).
+// The arithmetic is the device's, operation for operation (one f32 multiply, compare-selects, round to nearest even),
+// so a batch quantised here decodes bit for bit like the same batch ingested on the device.  Returns true when a -inf
+// was met: int8 has no code left for it, and the caller sends that chunk in its own format instead.
+bool nrldpc_quantise_i8(int8_t* dst, const void* src, size_t n, int src_kind, float scale);
+
+#endif

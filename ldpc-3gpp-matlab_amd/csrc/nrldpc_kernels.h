@@ -6,6 +6,7 @@
 
 #define NRLDPC_K_F32 0
 #define NRLDPC_K_F16 1
+#define NRLDPC_K_I8 2  // already on the fixed-point grid (the host path quantises while it copies): int8, -128 = +inf
 
 #ifndef NRLDPC_GEN_THREADS_BG1
 #define NRLDPC_GEN_THREADS_BG1 512 // workgroup size cap of the run-time-Z kernel for BG1

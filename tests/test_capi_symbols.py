@@ -43,6 +43,33 @@ def test_helpers_without_device(pkg):
     assert lib.nrldpc_strerror(1) == b"unsupported parameters"
 
 
+def test_host_quantiser_is_the_kernels_ingest(pkg):
+    """nrldpc_quantise_llr (what the host path puts on the wire) against a numpy restatement of the decoder kernels'
+    ingest(): f32 multiply by the scale, NaN -> 0, clamp to +-127, round to nearest even; +inf -> -128; -inf flagged.
+    All three boundary dtypes, every scale, sizes around the vector width."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for dt in (np.float64, np.float32, np.float16):
+        for scale in (1, 2, 4, 8, 16, 32):
+            for n in (1, 7, 8, 33, 1000, 4099):
+                x = (rng.standard_normal(n) * rng.choice([0.05, 1.0, 6.0, 40.0])).astype(dt)
+                k = rng.integers(0, n, 6)
+                x[k[0]] = np.nan; x[k[1]] = np.inf; x[k[2]] = (rng.integers(-300, 300) + 0.5) / scale
+                x[k[3]] = 127.5 / scale; x[k[4]] = -0.0
+                neg = bool(n > 8 and rng.integers(0, 2))
+                if neg:
+                    x[k[5]] = -np.inf
+                q, flag = pkg._capi.quantise_llr(x, scale)
+                x32 = x.astype(np.float32)
+                with np.errstate(invalid="ignore", over="ignore"):
+                    y = x32 * np.float32(scale)
+                y = np.where(np.isnan(y), np.float32(0), y)
+                ref = np.rint(np.clip(y, -127, 127)).astype(np.int8)
+                ref[x32 == np.inf] = -128
+                assert (q == ref).all(), (dt, scale, n)
+                assert flag == bool((x32 == -np.inf).any())
+
+
 def test_create_rejects_bad_parameters_before_touching_the_device(pkg):
     C = pkg._capi
     lib = pkg.load()

@@ -1,6 +1,8 @@
 """BASELINE.json's full sizes through size-independent properties (the oracle would need minutes):
 encode -> noise -> decode round trips on 4096-codeword batches, agreement between the host and the
 device entry points, oracle spot checks on a sample, and the mixed-(BG,Z) configuration."""
+import os
+
 import numpy as np
 import pytest
 
@@ -98,6 +100,17 @@ def test_pipelined_host_path_equals_one_device_launch(pkg, orc, dt, B):
     info = rng.integers(0, 2, (B, c.K), dtype=np.uint8)
     llr = awgn_llr(rng, c.encode(info), -0.3, dt, 384)
     assert llr.nbytes >= (32 << 20) * (2 if dt == np.float64 else 1)
+    # The copy threads quantise to int8 on the way into the pinned slots (nrldpc_quantise_llr): the values that could
+    # tell the host's arithmetic from the kernel's, in core and extension columns of a few codewords -- rounding ties,
+    # the clamp, NaN, +inf fillers (NRLDPCDecoder.m:264), and one -inf, whose chunk must travel in its own format.
+    odd = np.array([0.0625, -0.0625, 0.1875, -0.3125, 15.875, 15.9375, -15.9375, 1e4, -1e4, np.nan, np.inf, 1e-3, -0.0,
+                    0.06250001, 0.31249999], dtype=np.float64).astype(dt)
+    for b in (0, 3, B // 2, B - 1):
+        llr[b, 2 * 384 + 5: 2 * 384 + 5 + odd.size] = odd
+        llr[b, 30 * 384 + 7: 30 * 384 + 7 + odd.size] = odd
+        llr[b, 8000:8040] = np.inf
+    llr[B // 3, 9000] = -np.inf
+    llr[B // 3, 40 * 384 + 1] = -np.inf
     h1, it1 = c.decode(llr, want_iters=True)
     h2 = c.decode(llr)                                       # second call reuses the pinned slots
     dev_dt = np.float32 if dt == np.float64 else dt
@@ -110,6 +123,14 @@ def test_pipelined_host_path_equals_one_device_launch(pkg, orc, dt, B):
     c.close(); cd.close()
     assert (d_h.cpu().numpy() == h1).all() and (d_it.cpu().numpy() == it1).all() and (h2 == h1).all()
     assert (h1 != info).any(1).mean() < 0.05 and it1.min() < 12
+    os.environ["NRLDPC_HOST_I8"] = "0"                       # ... and what the native-format host path returns
+    try:
+        c = pkg.Codec(1, 384, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dt)
+        h3, it3 = c.decode(llr, want_iters=True)
+        c.close()
+    finally:
+        del os.environ["NRLDPC_HOST_I8"]
+    assert (h3 == h1).all() and (it3 == it1).all()
 
 
 def test_cfg4_mixed_batch_in_one_call_matches_the_oracle(pkg, orc):
