@@ -15,7 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip.so")  # env override: kernel experiments
 OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_channel.hip",
-           "nrldpc_capi.hip", "nrldpc_host_quant.cpp"]  # .cpp: host-only C++ (no device pass)
+           "nrldpc_expand.hip", "nrldpc_capi.hip", "nrldpc_host_quant.cpp"]  # .cpp: host-only C++ (no device pass)
 Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
 # = NRLDPC_Z64_LIST (nrldpc_kernels.h): the sizes where the compile-time-Z kernel beats the run-time-Z one
 Z64_BG1 = (60, 64, 104, 112, 120, 128, 144, 176, 192, 208, 224, 240, 256, 288, 320, 352, 384)

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -97,14 +99,14 @@ struct PinBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
 };
 
-// A few persistent host threads that move (and, for MATLAB doubles, narrow) the caller's pageable arrays
-// into / out of the pinned staging buffers: one core does not keep up with PCIe.
-// CPUs of the NUMA node the calling thread runs on (/sys/devices/system/node/node*/cpulist), empty if unknown.  The
-// caller's arrays were most likely first touched -- hence placed -- there; copy threads that wander to the other
-// socket of a two-socket host made the MATLAB-double path swing between 12 and 19 ms from one process to the next.
-static bool caller_node_cpus(cpu_set_t* out) {
-    const int me = sched_getcpu();
-    if (me < 0) return false;
+// A few persistent host threads that move (and quantise / narrow) the caller's pageable arrays into / out of the pinned
+// staging buffers: one core does not keep up with PCIe.  On a two-socket host they have to run on the NUMA node that
+// HOLDS the caller's array: threads on the other socket read it over the inter-socket links (~120 GB/s for everyone
+// together, measured: 855 MB of MATLAB doubles took 7 ms however many threads there were), and the node the calling thread
+// happens to run on says little about where its array was first touched.  So the pool asks the kernel where the array's
+// pages are (move_pages with no target nodes = query) and moves its threads there, per call.
+static int numa_cpus(std::vector<cpu_set_t>* out) { // CPUs of node 0, 1, ... (/sys/devices/system/node/node*/cpulist)
+    out->clear();
     for (int node = 0; node < 64; ++node) {
         char path[96];
         snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
@@ -113,21 +115,48 @@ static bool caller_node_cpus(cpu_set_t* out) {
         char buf[4096];
         const bool ok = fgets(buf, sizeof buf, f) != nullptr;
         fclose(f);
-        if (!ok) continue;
-        CPU_ZERO(out);
-        bool mine = false;
-        for (char* p = buf; *p && *p != '\n';) { // "0-63,128-191"
-            char* e;
-            const long a = strtol(p, &e, 10);
-            long b = a;
-            if (*e == '-') b = strtol(e + 1, &e, 10);
-            for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, out); mine |= (c == me); }
-            p = (*e == ',') ? e + 1 : e;
-            if (e == p && *e != ',') break;
-        }
-        if (mine) return true;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (ok)
+            for (char* p = buf; *p && *p != '\n';) { // "0-63,128-191"
+                char* e;
+                const long a = strtol(p, &e, 10);
+                long b = a;
+                if (*e == '-') b = strtol(e + 1, &e, 10);
+                for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &set);
+                p = (*e == ',') ? e + 1 : e;
+                if (e == p && *e != ',') break;
+            }
+        out->push_back(set);
     }
-    return false;
+    return (int)out->size();
+}
+
+// NUMA node that holds most of [p, p + bytes) (sampled), -1 if unknown
+static int numa_node_of(const void* p, size_t bytes) {
+#ifdef SYS_move_pages
+    const long page = sysconf(_SC_PAGESIZE);
+    if (page <= 0 || bytes == 0) return -1;
+    constexpr int NSAMP = 9;
+    void* addr[NSAMP];
+    int status[NSAMP];
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes - 1;
+    for (int i = 0; i < NSAMP; ++i) {
+        addr[i] = reinterpret_cast<void*>((lo + (uintptr_t)((double)(hi - lo) * i / (NSAMP - 1))) & ~(uintptr_t)(page - 1));
+        status[i] = -1;
+    }
+    if (syscall(SYS_move_pages, 0, (unsigned long)NSAMP, addr, nullptr, status, 0) != 0) return -1;
+    int votes[64] = {};
+    for (int i = 0; i < NSAMP; ++i)
+        if (status[i] >= 0 && status[i] < 64) ++votes[status[i]];
+    int best = -1;
+    for (int n = 0; n < 64; ++n)
+        if (votes[n] > 0 && (best < 0 || votes[n] > votes[best])) best = n;
+    return best;
+#else
+    (void)p; (void)bytes;
+    return -1;
+#endif
 }
 
 class HostPool {
@@ -151,12 +180,13 @@ class HostPool {
     }
 
 public:
+    std::vector<cpu_set_t> nodes_;
+    int node_ = -1;
+
     explicit HostPool(int n) {
-        cpu_set_t node;
-        const bool pin = getenv("NRLDPC_HOST_NO_PIN") == nullptr && caller_node_cpus(&node);
+        if (getenv("NRLDPC_HOST_NO_PIN") == nullptr) (void)numa_cpus(&nodes_);
         for (int i = 0; i < n; ++i)
-            th_.emplace_back([this, i, n, pin, node] {
-                if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof node, &node);
+            th_.emplace_back([this, i, n] {
                 unsigned seen = 0;
                 for (;;) {
                     const auto t0 = std::chrono::steady_clock::now();
@@ -184,6 +214,14 @@ public:
         }
         cv_.notify_all();
         for (auto& t : th_) t.join();
+    }
+    // Run the workers on the NUMA node that holds the caller's array (no-op when it is unknown or unchanged).
+    void follow(const void* p, size_t bytes) {
+        if (nodes_.size() < 2) return;
+        const int node = numa_node_of(p, bytes);
+        if (node < 0 || node >= (int)nodes_.size() || node == node_) return;
+        for (auto& t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(cpu_set_t), &nodes_[node]);
+        node_ = node;
     }
     // f(worker, nworkers) on every worker; returns when all are done
     void run(std::function<void(int, int)> f) {
@@ -238,6 +276,7 @@ struct nrldpc_codec {
     int step_nk[3] = {0, 0, 0}, step_kcol[3][3] = {}, step_kshift[3][3] = {}; // already-known core blocks in that row
     // host-entry staging
     DevBuf<char> s_llr;
+    DevBuf<int8_t> s_q; // int8 chunks of the pipelined host path, one region per slot
     DevBuf<uint8_t> s_hard, s_bits;
     DevBuf<int32_t> s_iters;
     DevBuf<float> s_app;
@@ -481,7 +520,7 @@ void nrldpc_destroy(nrldpc_handle h) {
     DeviceScope scope(h->cfg.device_id);
     h->d_rot.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
-    h->s_llr.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
+    h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
     for (int i = 0; i < 3; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
@@ -676,9 +715,9 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     const size_t in_bytes = (size_t)batch * ncw * eb;
     static const int env_chunk_mb = getenv("NRLDPC_HOST_CHUNK_MB") ? atoi(getenv("NRLDPC_HOST_CHUNK_MB")) : 32;
     static const int env_threads = getenv("NRLDPC_HOST_THREADS") ? atoi(getenv("NRLDPC_HOST_THREADS")) : 16;
-    // The copy threads quantise while they copy (1 byte per LLR on the wire instead of 2 / 4; nrldpc_host_quant.h): the
-    // kernels that read the int8 format are the compile-time-Z ones.  NRLDPC_HOST_I8=0: A/B against the native format.
-    const bool i8 = nrldpc::has_z64_kernel(s.g.bg, s.Z) && !(getenv("NRLDPC_HOST_I8") && atoi(getenv("NRLDPC_HOST_I8")) == 0);
+    // The copy threads quantise while they copy (1 byte per LLR on the wire instead of 2 / 4; nrldpc_host_quant.h) and a
+    // small kernel expands each chunk to fp16 on the device (nrldpc_expand.hip).  NRLDPC_HOST_I8=0: A/B against the native format.
+    const bool i8 = !(getenv("NRLDPC_HOST_I8") && atoi(getenv("NRLDPC_HOST_I8")) == 0);
     const int hq_kind = f64 ? NRLDPC_HQ_F64 : h->cfg.llr_dtype == NRLDPC_LLR_F16 ? NRLDPC_HQ_F16 : NRLDPC_HQ_F32;
     const size_t host_eb = f64 ? 8 : eb; // element size of the caller's array
     static const int env_pipe = getenv("NRLDPC_HOST_PIPELINE") ? atoi(getenv("NRLDPC_HOST_PIPELINE")) : 1;
@@ -702,9 +741,12 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
             if (iters_out) HIP_TRY(h->pin_it[i].reserve((size_t)chunk * 4));
             if (!h->xdone[i]) HIP_TRY(hipEventCreateWithFlags(&h->xdone[i], hipEventDisableTiming));
         }
+        const size_t q_slot = ((size_t)chunk * ncw + 255) & ~(size_t)255; // bytes of one int8 chunk on the device
+        if (i8) HIP_TRY(h->s_q.reserve(q_slot * NS));
         for (int i = 0; i < 2; ++i)
             if (!h->xs[i]) HIP_TRY(hipStreamCreateWithFlags(&h->xs[i], hipStreamNonBlocking));
         const int nchunks = (batch + chunk - 1) / chunk;
+        h->pool->follow(llr, (size_t)batch * ncw * host_eb);
         // an early error return must not leave copies or kernels of this call in flight on the two streams
         struct Quiesce {
             hipStream_t* xs; bool armed = true;
@@ -738,8 +780,10 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
             const double tq0 = now();
             if (i8 && !h->pool->quantise(reinterpret_cast<int8_t*>(h->pin_in[sl].p), static_cast<const char*>(llr) + off * host_eb,
                                          (size_t)n * ncw, hq_kind, (float)h->scale)) {
-                kind = NRLDPC_K_I8;
-                HIP_TRY(hipMemcpyAsync(d_in, h->pin_in[sl].p, (size_t)n * ncw, hipMemcpyHostToDevice, h->xs[st]));
+                kind = NRLDPC_K_F16; // whatever the handle's format: this chunk reaches the decoder as fp16
+                int8_t* d_q = h->s_q.p + q_slot * sl;
+                HIP_TRY(hipMemcpyAsync(d_q, h->pin_in[sl].p, (size_t)n * ncw, hipMemcpyHostToDevice, h->xs[st]));
+                HIP_TRY(nrldpc::launch_expand_i8(d_q, d_in, (size_t)n * ncw, 1.0f / (float)h->scale, h->xs[st]));
             } else { // (a chunk that holds a -inf has no int8 form)
                 if (f64) h->pool->move(h->pin_in[sl].p, static_cast<const double*>(llr) + off, (size_t)n * ncw, true);
                 else h->pool->move(h->pin_in[sl].p, static_cast<const char*>(llr) + off * eb, (size_t)n * ncw * eb, false);
@@ -756,8 +800,8 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
         }
         for (; drained < nchunks; ++drained) { int rc = drain(drained); if (rc) return rc; }
         if (trace)
-            fprintf(stderr, "[nrldpc host path] %d chunks of %d: copy/quantise in %.2f ms (incl. H2D enqueue), launch+D2H enqueue %.2f, wait for device %.2f, copy out %.2f\n",
-                    nchunks, chunk, t_quant, t_enq, t_wait, t_out);
+            fprintf(stderr, "[nrldpc host path] %d chunks of %d: copy/quantise in %.2f ms (incl. H2D enqueue), launch+D2H enqueue %.2f, wait for device %.2f, copy out %.2f; copy threads on NUMA node %d (caller on CPU %d)\n",
+                    nchunks, chunk, t_quant, t_enq, t_wait, t_out, h->pool->node_, sched_getcpu());
         quiesce.armed = false; // every chunk was drained behind its event
         return NRLDPC_OK;
     }

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
     if (active) {
         const size_t base = (size_t)cw * ncwz;
         if (a.app) app_row = a.app + base + z;
-        const bool f16 = a.llr_kind == NRLDPC_K_F16, i8 = a.llr_kind == NRLDPC_K_I8;
+        const bool f16 = a.llr_kind == NRLDPC_K_F16;
         char* home = lds + cwbase + G::GUARD + 4 * z; // ring position z of column 0
         // Core columns -> LDS.  A quarter of the codeword's threads covers one column with 4 consecutive ring
         // positions each (8- or 16-byte loads, ds_write_b128), four columns per pass: 7 load instructions per
@@ -539,10 +539,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
                 x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (4 * k + 3 < G::NC || c < G::NC) {
                     const size_t i = base + (size_t)c * ZC + 4 * qq;
-                    if (i8) {
-                        const uint32_t r = *reinterpret_cast<const uint32_t*>(static_cast<const int8_t*>(a.llr) + i);
-                        x[k] = make_float4(byte_to_f32<0>(r), byte_to_f32<1>(r), byte_to_f32<2>(r), byte_to_f32<3>(r));
-                    } else if (f16) {
+                    if (f16) {
                         const uint2 r = *reinterpret_cast<const uint2*>(static_cast<const __half*>(a.llr) + i);
                         const __half2 lo = *reinterpret_cast<const __half2*>(&r.x), hi = *reinterpret_cast<const __half2*>(&r.y);
                         x[k] = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
@@ -555,9 +552,8 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
                 constexpr int k = decltype(kc)::value;
                 const int c = 4 * k + qs;
                 if (4 * k + 3 < G::NC || c < G::NC) {
-                    const float4 q = i8 ? make_float4(ingest_q(x[k].x, true), ingest_q(x[k].y, true), ingest_q(x[k].z, true), ingest_q(x[k].w, true))
-                                        : make_float4(ingest(x[k].x, a.scale, true), ingest(x[k].y, a.scale, true),
-                                                      ingest(x[k].z, a.scale, true), ingest(x[k].w, a.scale, true));
+                    const float4 q = make_float4(ingest(x[k].x, a.scale, true), ingest(x[k].y, a.scale, true),
+                                                 ingest(x[k].z, a.scale, true), ingest(x[k].w, a.scale, true));
                     char* col = lds + cwbase + G::GUARD + c * G::CS;
                     *reinterpret_cast<float4*>(col + 16 * qq) = q;
                     if (qq < 16) *reinterpret_cast<float4*>(col + 4 * ZC + 16 * qq) = q; // mirror of block 0
@@ -568,11 +564,11 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             static_for<G::NC>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 const size_t i = base + (size_t)c * ZC + z;
-                x[c] = i8 ? load_llr<NRLDPC_K_I8>(a.llr, i) : f16 ? load_llr<NRLDPC_K_F16>(a.llr, i) : load_llr<NRLDPC_K_F32>(a.llr, i);
+                x[c] = f16 ? load_llr<NRLDPC_K_F16>(a.llr, i) : load_llr<NRLDPC_K_F32>(a.llr, i);
             });
             static_for<G::NC>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                const float q = i8 ? ingest_q(x[c], true) : ingest(x[c], a.scale, true);
+                const float q = ingest(x[c], a.scale, true);
                 *reinterpret_cast<float*>(home + c * G::CS) = q;
                 if (w == 0) *reinterpret_cast<float*>(home + c * G::CS + ZC * 4) = q; // mirror of block 0
             });
@@ -589,7 +585,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
                     static_for<i1 - i0>([&](auto ic) {
                         constexpr int i = i0 + decltype(ic)::value;
                         const size_t gi = base + (size_t)(G::NC + i) * ZC + z;
-                        x[i] = i8 ? load_llr<NRLDPC_K_I8>(a.llr, gi) : f16 ? load_llr<NRLDPC_K_F16>(a.llr, gi) : load_llr<NRLDPC_K_F32>(a.llr, gi);
+                        x[i] = f16 ? load_llr<NRLDPC_K_F16>(a.llr, gi) : load_llr<NRLDPC_K_F32>(a.llr, gi);
                     });
                 } else {
                     static_for<i1 - i0>([&](auto ic) { x[i0 + decltype(ic)::value] = 0.0f; });
@@ -597,7 +593,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             });
             static_for<G::NEXT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                f32_to_byte<i & 3>(st.xq[i >> 2], i8 ? ingest_q(x[i], false) : ingest(x[i], a.scale, false));
+                f32_to_byte<i & 3>(st.xq[i >> 2], ingest(x[i], a.scale, false));
             });
         }
         if (app_row) {

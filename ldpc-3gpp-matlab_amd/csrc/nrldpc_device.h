@@ -139,8 +139,6 @@ template <int B> __device__ __forceinline__ void f32_to_byte(uint32_t& w, float 
 template <int DT> __device__ __forceinline__ float load_llr(const void* p, size_t i) {
     if constexpr (DT == NRLDPC_K_F16)
         return __half2float(static_cast<const __half*>(p)[i]);
-    else if constexpr (DT == NRLDPC_K_I8)
-        return (float)static_cast<const int8_t*>(p)[i];
     else
         return static_cast<const float*>(p)[i];
 }
@@ -163,12 +161,6 @@ __device__ __forceinline__ float ingest(float x, float scale, bool core) {
 __device__ __forceinline__ float scale_mag(const DecArgs& a, float m) {
     const float y = __builtin_fmaf(a.alpha, m, 8388608.0f - a.beta);
     return __builtin_amdgcn_fmed3f(y, 8388608.0f, 8388608.0f + 127.0f) - 8388608.0f;
-}
-
-// The same for an LLR that was quantised on the host (NRLDPC_K_I8: the value of ingest() as int8, +inf as -128; -inf
-// never arrives this way, the host path keeps such batches in their own format).
-__device__ __forceinline__ float ingest_q(float q, bool core) {
-    return q == -128.0f ? (core ? 1048576.0f : 127.0f) : q;
 }
 
 template <int BG> struct DecState {

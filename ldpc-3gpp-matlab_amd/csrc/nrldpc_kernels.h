@@ -6,7 +6,6 @@
 
 #define NRLDPC_K_F32 0
 #define NRLDPC_K_F16 1
-#define NRLDPC_K_I8 2  // already on the fixed-point grid (the host path quantises while it copies): int8, -128 = +inf
 
 #ifndef NRLDPC_GEN_THREADS_BG1
 #define NRLDPC_GEN_THREADS_BG1 512 // workgroup size cap of the run-time-Z kernel for BG1
@@ -137,6 +136,9 @@ struct ChanArgs {
     float sigma, inv_n0, inv_norm; // sqrt(N0/2); 1/N0; 1/sqrt(2 mean(level^2)) of one rail
 };
 hipError_t launch_awgn_llr(const ChanArgs& a, hipStream_t stream);
+
+// int8 wire format of the host path (nrldpc_host_quant.h) -> fp16 LLRs the decoder kernels ingest (nrldpc_expand.hip)
+hipError_t launch_expand_i8(const int8_t* d_q, void* d_out_f16, size_t n, float inv_scale, hipStream_t stream);
 
 } // namespace nrldpc
 #endif

@@ -89,32 +89,33 @@ def test_host_and_device_entry_points_agree(pkg, orc):
     assert (d_h.cpu().numpy() == h1).all() and (d_it.cpu().numpy() == it1).all()
 
 
-@pytest.mark.parametrize("dt,B", [(np.float64, 1237), (np.float32, 1001), (np.float16, 2049)])
-def test_pipelined_host_path_equals_one_device_launch(pkg, orc, dt, B):
+@pytest.mark.parametrize("dt,B,bg,Z", [(np.float64, 1237, 1, 384), (np.float32, 1001, 1, 384), (np.float16, 2049, 1, 384),
+                                        (np.float32, 9001, 2, 20), (np.float64, 3001, 1, 36)])  # ... and two run-time-Z sizes
+def test_pipelined_host_path_equals_one_device_launch(pkg, orc, dt, B, bg, Z):
     """Batches above 32 MB take the chunked, double-buffered host path of nrldpc_decode (pinned staging, copy
     threads, two streams); it must return exactly what one device launch on the same LLRs returns, for a
     batch that is not a multiple of the chunk size and for every boundary dtype (MATLAB doubles included)."""
     import torch
     rng = np.random.default_rng(B)
-    c = pkg.Codec(1, 384, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dt)
+    c = pkg.Codec(bg, Z, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dt)
     info = rng.integers(0, 2, (B, c.K), dtype=np.uint8)
-    llr = awgn_llr(rng, c.encode(info), -0.3, dt, 384)
-    assert llr.nbytes >= (32 << 20) * (2 if dt == np.float64 else 1)
+    llr = awgn_llr(rng, c.encode(info), -0.3 if Z == 384 else 1.5, dt, Z)
+    assert llr.nbytes >= (8 << 20) * (2 if dt == np.float64 else 1)  # the pipelined path starts at 8 MB of device-format input
     # The copy threads quantise to int8 on the way into the pinned slots (nrldpc_quantise_llr): the values that could
     # tell the host's arithmetic from the kernel's, in core and extension columns of a few codewords -- rounding ties,
     # the clamp, NaN, +inf fillers (NRLDPCDecoder.m:264), and one -inf, whose chunk must travel in its own format.
     odd = np.array([0.0625, -0.0625, 0.1875, -0.3125, 15.875, 15.9375, -15.9375, 1e4, -1e4, np.nan, np.inf, 1e-3, -0.0,
                     0.06250001, 0.31249999], dtype=np.float64).astype(dt)
     for b in (0, 3, B // 2, B - 1):
-        llr[b, 2 * 384 + 5: 2 * 384 + 5 + odd.size] = odd
-        llr[b, 30 * 384 + 7: 30 * 384 + 7 + odd.size] = odd
-        llr[b, 8000:8040] = np.inf
-    llr[B // 3, 9000] = -np.inf
-    llr[B // 3, 40 * 384 + 1] = -np.inf
+        llr[b, 2 * Z + 5: 2 * Z + 5 + odd.size] = odd
+        llr[b, 30 * Z + 7: 30 * Z + 7 + odd.size] = odd
+        llr[b, 8 * Z:8 * Z + 11] = np.inf
+    llr[B // 3, 9 * Z + 3] = -np.inf
+    llr[B // 3, 40 * Z + 1] = -np.inf
     h1, it1 = c.decode(llr, want_iters=True)
     h2 = c.decode(llr)                                       # second call reuses the pinned slots
     dev_dt = np.float32 if dt == np.float64 else dt
-    cd = pkg.Codec(1, 384, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dev_dt)
+    cd = pkg.Codec(bg, Z, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dev_dt)
     d_llr = torch.from_numpy(llr.astype(dev_dt)).cuda()
     d_h = torch.empty((B, c.K), dtype=torch.uint8, device="cuda")
     d_it = torch.empty(B, dtype=torch.int32, device="cuda")
@@ -122,10 +123,10 @@ def test_pipelined_host_path_equals_one_device_launch(pkg, orc, dt, B):
     torch.cuda.synchronize()
     c.close(); cd.close()
     assert (d_h.cpu().numpy() == h1).all() and (d_it.cpu().numpy() == it1).all() and (h2 == h1).all()
-    assert (h1 != info).any(1).mean() < 0.05 and it1.min() < 12
+    assert (h1 != info).any(1).mean() < (0.05 if Z == 384 else 0.5) and it1.min() < 12
     os.environ["NRLDPC_HOST_I8"] = "0"                       # ... and what the native-format host path returns
     try:
-        c = pkg.Codec(1, 384, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dt)
+        c = pkg.Codec(bg, Z, max_iter=12, early_term=True, alpha=0.625, llr_dtype=dt)
         h3, it3 = c.decode(llr, want_iters=True)
         c.close()
     finally:
@@ -164,11 +165,12 @@ def test_cfg4_mixed_batch_in_one_call_matches_the_oracle(pkg, orc):
         codecs.append(c); llrs.append(llr); ns.append(n); ref_h.append(h); ref_i.append(it); host_llr.append(x[:2])
     out_h = [torch.zeros_like(h) for h in ref_h]
     out_i = [torch.zeros_like(i) for i in ref_i]
+    out_h2 = [torch.zeros_like(h) for h in ref_h]
+    torch.cuda.synchronize()  # the zero fills run on the current stream; s2 below does not wait for that stream
     pkg.decode_multi_dev(codecs, [x.data_ptr() for x in llrs], ns, [x.data_ptr() for x in out_h],
                          [x.data_ptr() for x in out_i], s)
     # a second call on another stream while the first may still be running: each call has its own table slot
     s2 = torch.cuda.Stream()
-    out_h2 = [torch.zeros_like(h) for h in ref_h]
     pkg.decode_multi_dev(codecs, [x.data_ptr() for x in llrs], ns, [x.data_ptr() for x in out_h2], None, s2.cuda_stream)
     torch.cuda.synchronize()
     for k, c in enumerate(codecs):
