@@ -64,6 +64,18 @@ def _profile():
     return None, {}, {}
 
 
+def isa_mix_ns_per_iteration_wave():
+    """Sum of (count x measured issue interval) over the VALU opcodes of the headline kernel's iteration loop, from the
+    committed static profile (first block = BG1 Z=384)."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r02_headline_isa_mix.txt")):
+            if line.startswith("sum "):
+                return float(line.split()[-1])
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def bler_match():
     """Second half of the metric ('BLER match vs MATLAB ref'): the dB gap to flooding sum-product (the reference's
     semantics) at equal iteration caps, measured by tests/test_bler_gap_gpu.py on identical noise and committed under
@@ -301,6 +313,14 @@ def main():
                           "2.4 GHz / 2 cycles per wave64 VALU op; instruction counts are per launch and "
                           "data-independent without early termination" % tag,
             }
+            # the same bound with every opcode of the iteration loop priced at its measured issue interval (tools/isa_mix.py,
+            # static: disassembly x profiles/r02_ubench_valu_rates.txt): time the loop needs if the VALU pipes never idle
+            mix = isa_mix_ns_per_iteration_wave()
+            if mix:
+                valu_ms = mix * 3.0 * ITERS * (batch / 2.0 / 256.0) * 1e-6  # 3 waves per SIMD, 256 CUs x 2 codewords per round
+                secondary["cycle_weighted"] = {
+                    "valu_ns_per_iteration_and_wave": mix, "valu_bound_ms_per_launch": valu_ms, "frac": valu_ms / kernel_ms,
+                    "source": "profiles/r02_headline_isa_mix.txt"}
         out = {
             "metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
             "value": value, "unit": "Gbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -159,6 +159,24 @@ static int numa_node_of(const void* p, size_t bytes) {
 #endif
 }
 
+// CPUs this process may actually use: the cgroup CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) when
+// there is one, else what the scheduler reports.
+static int usable_cpus() {
+    long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+        fclose(f);
+    } else {
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+    }
+    const unsigned hc = std::thread::hardware_concurrency();
+    int n = hc ? (int)hc : 8;
+    if (quota > 0 && period > 0) n = std::min(n, (int)((quota + period - 1) / period));
+    return std::max(1, n);
+}
+
 class HostPool {
     // Fork/join on every chunk of a pipelined call: a dozen jobs of 0.1-0.4 ms each within a few milliseconds.  Waking
     // sixteen sleeping threads through a condition variable costs 0.15-0.2 ms per job (measured: 13 chunks x 2 jobs made
@@ -166,13 +184,21 @@ class HostPool {
     // to sleep, and the caller polls the completion counter.
     std::vector<std::thread> th_;
     std::mutex m_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, cv_done_;
     std::function<void(int, int)> job_;
+    std::atomic<int> caller_sleeps_{0};
     std::atomic<unsigned> gen_{0};
     std::atomic<int> pending_{0};
     std::atomic<int> sleepers_{0};
     std::atomic<bool> stop_{false};
 
+    // NRLDPC_HOST_SPIN_US: how long an idle copy thread polls for the next job before it sleeps.  Default 0: polling
+    // saves ~0.1 ms per job on an idle host, but a container with a CPU quota (the MI355X boxes of this build: 256 CPUs
+    // visible, cpu.max = 16) charges polling like work, and a throttled process loses 20-30 ms at a time.
+    static int spin_us() {
+        static const int v = getenv("NRLDPC_HOST_SPIN_US") ? atoi(getenv("NRLDPC_HOST_SPIN_US")) : 0;
+        return v;
+    }
     static void relax() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -193,7 +219,7 @@ public:
                     int polls = 0;
                     while (gen_.load(std::memory_order_acquire) == seen && !stop_.load(std::memory_order_relaxed)) {
                         relax();
-                        if ((++polls & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) {
+                        if (((++polls & 255) == 0 || spin_us() == 0) && std::chrono::steady_clock::now() - t0 >= std::chrono::microseconds(spin_us())) {
                             std::unique_lock<std::mutex> lk(m_);
                             sleepers_.fetch_add(1);
                             cv_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
@@ -203,7 +229,10 @@ public:
                     if (stop_.load()) return;
                     seen = gen_.load(std::memory_order_acquire);
                     job_(i, n); // published before the generation moved; the next run() starts only after this one is done
-                    pending_.fetch_sub(1, std::memory_order_acq_rel);
+                    if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1 && caller_sleeps_.load() != 0) {
+                        std::lock_guard<std::mutex> lk(m_);
+                        cv_done_.notify_all();
+                    }
                 }
             });
     }
@@ -232,7 +261,19 @@ public:
             gen_.fetch_add(1, std::memory_order_release);
         }
         if (sleepers_.load() > 0) cv_.notify_all();
-        while (pending_.load(std::memory_order_acquire) != 0) relax();
+        // poll for the usual sub-millisecond job; on an oversubscribed host (several handles decoding at once, each with
+        // its own pool) give the core away instead
+        const auto t0 = std::chrono::steady_clock::now();
+        int polls = 0;
+        while (pending_.load(std::memory_order_acquire) != 0) {
+            relax();
+            if (((++polls & 255) == 0 || spin_us() == 0) && std::chrono::steady_clock::now() - t0 >= std::chrono::microseconds(5 * spin_us())) {
+                std::unique_lock<std::mutex> lk(m_);
+                caller_sleeps_.store(1);
+                cv_done_.wait_for(lk, std::chrono::milliseconds(2), [&] { return pending_.load() == 0; });
+                caller_sleeps_.store(0);
+            }
+        }
     }
     // dst[i] = int8 grid value of src[i] (nrldpc_host_quant.h) for n elements; true when a -inf was met
     bool quantise(int8_t* dst, const void* src, size_t n, int kind, float scale) {
@@ -298,6 +339,7 @@ struct nrldpc_codec {
     hipStream_t xs[2] = {nullptr, nullptr};
     hipEvent_t xdone[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     HostPool* pool = nullptr;
+    int host_threads_hint = 0; // > 0: copy threads of this handle (nrldpc_pool_* shares the cores between its handles)
     // timing
     bool timing = false, have_time = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -731,8 +773,9 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
         int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, chunk_bytes / (ncw * wire_eb)));
         if (chunk >= 512) chunk -= chunk % 512;
         if (!h->pool) {
-            const unsigned hc = std::thread::hardware_concurrency();
-            h->pool = new (std::nothrow) HostPool((int)std::max(1u, std::min((unsigned)std::max(1, env_threads), hc ? hc / 2 : 4u)));
+            // the caller's own thread works too (enqueues, waits for events): leave it a CPU of the quota
+            const int want = h->host_threads_hint > 0 ? h->host_threads_hint : std::max(1, env_threads);
+            h->pool = new (std::nothrow) HostPool(std::max(1, std::min(want, usable_cpus() - 1)));
             if (!h->pool) return fail(NRLDPC_ERR_NOMEM, "host thread pool");
         }
         for (int i = 0; i < NS; ++i) {
@@ -894,6 +937,7 @@ int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t
             delete p;
             return rc; // text of nrldpc_create's failure is already in place
         }
+        h->host_threads_hint = std::max(2, 16 / n_devices);
         p->hs.push_back(h);
     }
     const nrldpc::Schedule& s = p->hs[0]->sched;
