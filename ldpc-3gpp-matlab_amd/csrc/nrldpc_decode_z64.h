@@ -522,80 +522,104 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
     if (active) {
         const size_t base = (size_t)cw * ncwz;
         if (a.app) app_row = a.app + base + z;
-        const bool f16 = a.llr_kind == NRLDPC_K_F16;
         char* home = lds + cwbase + G::GUARD + 4 * z; // ring position z of column 0
         // Core columns -> LDS.  A quarter of the codeword's threads covers one column with 4 consecutive ring
         // positions each (8- or 16-byte loads, ds_write_b128), four columns per pass: 7 load instructions per
         // thread instead of 26 two-byte ones.  Unaligned LLR pointers take the one-position-per-thread path.
+        // Extension columns -> registers, one load per column and thread.
+        //
+        // All loads of a thread are issued as RAW bits before the first one is converted, in a body instantiated per LLR
+        // format: with the format tested per load (the first version of this prologue) the fp16 branch converted right
+        // behind its load, so every one of the 49 loads of a thread was its own HBM round trip -- 19 us per workgroup,
+        // one iteration's worth, against ~7 us now.
         constexpr int QW = ZC / 4;
         const int qs = z / QW, qq = z - qs * QW; // column within a pass, quad within the column
         const bool wide = (reinterpret_cast<uintptr_t>(a.llr) & 15) == 0;
-        if (wide) {
-            constexpr int NP = (G::NC + 3) / 4;
-            float4 x[NP];
-            static_for<NP>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const int c = 4 * k + qs;
-                x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (4 * k + 3 < G::NC || c < G::NC) {
-                    const size_t i = base + (size_t)c * ZC + 4 * qq;
-                    if (f16) {
-                        const uint2 r = *reinterpret_cast<const uint2*>(static_cast<const __half*>(a.llr) + i);
-                        const __half2 lo = *reinterpret_cast<const __half2*>(&r.x), hi = *reinterpret_cast<const __half2*>(&r.y);
-                        x[k] = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
+        // The extension-parity LLR of a pruned row is never used (only soft output echoes it): at R = 8/9
+        // that is 41 of 68 columns of HBM input saved.  Blocks of 8 rows, wave-uniform branches.
+        const int next_used = a.app ? G::NEXT : FULL ? NL - 4 : launder(a.n_layers) - 4;
+        auto ingest_as = [&](auto kind_c) {
+            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
+            auto raw = [&](size_t i) -> uint32_t { // one LLR, raw bits
+                if constexpr (F16) return static_cast<const uint16_t*>(a.llr)[i];
+                else return static_cast<const uint32_t*>(a.llr)[i];
+            };
+            auto val = [&](uint32_t r) -> float {
+                if constexpr (F16) return __half2float(__ushort_as_half((unsigned short)r));
+                else return __uint_as_float(r);
+            };
+            uint32_t xe[G::NEXT];
+            auto load_ext = [&]() {
+                static_for<(G::NEXT + 7) / 8>([&](auto bc) {
+                    constexpr int i0 = decltype(bc)::value * 8;
+                    constexpr int i1 = i0 + 8 < G::NEXT ? i0 + 8 : G::NEXT;
+                    if ((FULL && NL == G::ROWS) || i0 < next_used) {
+                        static_for<i1 - i0>([&](auto ic) {
+                            constexpr int i = i0 + decltype(ic)::value;
+                            xe[i] = raw(base + (size_t)(G::NC + i) * ZC + z);
+                        });
                     } else {
-                        x[k] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.llr) + i);
+                        static_for<i1 - i0>([&](auto ic) { xe[i0 + decltype(ic)::value] = 0u; });
                     }
-                }
-            });
-            static_for<NP>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const int c = 4 * k + qs;
-                if (4 * k + 3 < G::NC || c < G::NC) {
-                    const float4 q = make_float4(ingest(x[k].x, a.scale, true), ingest(x[k].y, a.scale, true),
-                                                 ingest(x[k].z, a.scale, true), ingest(x[k].w, a.scale, true));
-                    char* col = lds + cwbase + G::GUARD + c * G::CS;
-                    *reinterpret_cast<float4*>(col + 16 * qq) = q;
-                    if (qq < 16) *reinterpret_cast<float4*>(col + 4 * ZC + 16 * qq) = q; // mirror of block 0
-                }
-            });
-        } else {
-            float x[G::NC];
-            static_for<G::NC>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                const size_t i = base + (size_t)c * ZC + z;
-                x[c] = f16 ? load_llr<NRLDPC_K_F16>(a.llr, i) : load_llr<NRLDPC_K_F32>(a.llr, i);
-            });
-            static_for<G::NC>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                const float q = ingest(x[c], a.scale, true);
-                *reinterpret_cast<float*>(home + c * G::CS) = q;
-                if (w == 0) *reinterpret_cast<float*>(home + c * G::CS + ZC * 4) = q; // mirror of block 0
-            });
-        }
-        {
-            // The extension-parity LLR of a pruned row is never used (only soft output echoes it): at R = 8/9
-            // that is 41 of 68 columns of HBM input saved.  Blocks of 8 rows, wave-uniform branches.
-            float x[G::NEXT];
-            const int next_used = a.app ? G::NEXT : FULL ? NL - 4 : launder(a.n_layers) - 4;
-            static_for<(G::NEXT + 7) / 8>([&](auto bc) {
-                constexpr int i0 = decltype(bc)::value * 8;
-                constexpr int i1 = i0 + 8 < G::NEXT ? i0 + 8 : G::NEXT;
-                if ((FULL && NL == G::ROWS) || i0 < next_used) {
-                    static_for<i1 - i0>([&](auto ic) {
-                        constexpr int i = i0 + decltype(ic)::value;
-                        const size_t gi = base + (size_t)(G::NC + i) * ZC + z;
-                        x[i] = f16 ? load_llr<NRLDPC_K_F16>(a.llr, gi) : load_llr<NRLDPC_K_F32>(a.llr, gi);
-                    });
-                } else {
-                    static_for<i1 - i0>([&](auto ic) { x[i0 + decltype(ic)::value] = 0.0f; });
-                }
-            });
+                });
+            };
+            if (wide) {
+                constexpr int NP = (G::NC + 3) / 4;
+                uint4 x[NP];
+                static_for<NP>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const int c = 4 * k + qs;
+                    x[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (4 * k + 3 < G::NC || c < G::NC) {
+                        const size_t i = base + (size_t)c * ZC + 4 * qq;
+                        if constexpr (F16) {
+                            const uint2 r = *reinterpret_cast<const uint2*>(static_cast<const __half*>(a.llr) + i);
+                            x[k].x = r.x; x[k].y = r.y;
+                        } else {
+                            x[k] = *reinterpret_cast<const uint4*>(static_cast<const float*>(a.llr) + i);
+                        }
+                    }
+                });
+                load_ext();
+                static_for<NP>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const int c = 4 * k + qs;
+                    if (4 * k + 3 < G::NC || c < G::NC) {
+                        float4 v;
+                        if constexpr (F16) {
+                            const __half2 lo = *reinterpret_cast<const __half2*>(&x[k].x), hi = *reinterpret_cast<const __half2*>(&x[k].y);
+                            v = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
+                        } else {
+                            v = make_float4(__uint_as_float(x[k].x), __uint_as_float(x[k].y), __uint_as_float(x[k].z), __uint_as_float(x[k].w));
+                        }
+                        const float4 q = make_float4(ingest(v.x, a.scale, true), ingest(v.y, a.scale, true),
+                                                     ingest(v.z, a.scale, true), ingest(v.w, a.scale, true));
+                        char* col = lds + cwbase + G::GUARD + c * G::CS;
+                        *reinterpret_cast<float4*>(col + 16 * qq) = q;
+                        if (qq < 16) *reinterpret_cast<float4*>(col + 4 * ZC + 16 * qq) = q; // mirror of block 0
+                    }
+                });
+            } else {
+                uint32_t x[G::NC];
+                static_for<G::NC>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    x[c] = raw(base + (size_t)c * ZC + z);
+                });
+                load_ext();
+                static_for<G::NC>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    const float q = ingest(val(x[c]), a.scale, true);
+                    *reinterpret_cast<float*>(home + c * G::CS) = q;
+                    if (w == 0) *reinterpret_cast<float*>(home + c * G::CS + ZC * 4) = q; // mirror of block 0
+                });
+            }
             static_for<G::NEXT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                f32_to_byte<i & 3>(st.xq[i >> 2], ingest(x[i], a.scale, false));
+                f32_to_byte<i & 3>(st.xq[i >> 2], ingest(val(xe[i]), a.scale, false));
             });
-        }
+        };
+        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
         if (app_row) {
             static_for<G::NEXT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
