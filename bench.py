@@ -347,12 +347,16 @@ def main():
             "bler_match": bler_match(),
         }
         if world == 1:  # CPU baseline and host-path legs at N = 1 only
+            # the host-path leg first: the all-core CPU baselines spend the process's CPU quota (the MI355X boxes grant 16
+            # CPUs of the 256 they show) and a throttled process measures the throttle, not the path
+            if not args.no_e2e:
+                e2e = e2e_host_path(nrldpc, info.cpu().numpy(), llr.cpu().numpy(), rule)
+                e2e["note"] = "host pointers in and out (PCIe + host copies included); never `value`"
             if args.cpu_sample > 0:
                 n = min(args.cpu_sample, batch)
                 out["cpu_baseline"] = cpu_baseline(llr[:n].double().cpu().numpy(), info[:n].cpu().numpy(), rule)
             if not args.no_e2e:
-                out["e2e"] = e2e_host_path(nrldpc, info.cpu().numpy(), llr.cpu().numpy(), rule)
-                out["e2e"]["note"] = "host pointers in and out (PCIe + host copies included); never `value`"
+                out["e2e"] = e2e
         print(json.dumps(out), flush=True)
     codec.close()
     if dist is not None:
