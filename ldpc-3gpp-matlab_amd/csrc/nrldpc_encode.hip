@@ -137,7 +137,25 @@ __global__ __launch_bounds__(256) void nrldpc_encode_kernel(const EncArgs a) {
     };
     auto bit_of = [&](const uint32_t* P, int z) { return (P[z >> 5] >> (z & 31)) & 1u; };
 
-    pack(info, 0, kb);
+    // Z a multiple of 32 (every large lifting size): a ring word is 32 consecutive bytes of a column, so a lane builds
+    // whole words from two 16-byte loads -- ((w & 0x01010101) * 0x01020408) >> 24 squeezes 4 byte-bits into a nibble -- instead
+    // of one byte load and one ballot per bit: 264 word items per codeword at Z = 384 against 286 byte loads + ballots per lane.
+    const bool words32 = (Z & 31) == 0;
+    auto squeeze = [](uint32_t w) { return ((w & 0x01010101u) * 0x01020408u) >> 24; };
+    auto put_word = [&](int c, int m, uint32_t v) { // ring word m of column c into every slot of the doubled ring it fills
+        for (int w = m; w < DW; w += W) D[c * DW + w] = v;
+    };
+    if (words32 && (reinterpret_cast<uintptr_t>(info) & 15) == 0) {
+        for (int it = lane; it < kb * W; it += 64) {
+            const int c = it / W, m = it - c * W;
+            const uint4* s4 = reinterpret_cast<const uint4*>(info + (size_t)c * Z + 32 * m);
+            const uint4 lo = s4[0], hi = s4[1];
+            put_word(c, m, squeeze(lo.x) | squeeze(lo.y) << 4 | squeeze(lo.z) << 8 | squeeze(lo.w) << 12 |
+                               squeeze(hi.x) << 16 | squeeze(hi.y) << 20 | squeeze(hi.z) << 24 | squeeze(hi.w) << 28);
+        }
+    } else {
+        pack(info, 0, kb);
+    }
     wave_lds_sync();
     // 3a. lambda_i = systematic part of core row i
     for (int it = lane; it < 4 * W; it += 64) {
@@ -162,7 +180,19 @@ __global__ __launch_bounds__(256) void nrldpc_encode_kernel(const EncArgs a) {
         wave_lds_sync();
     }
     store_row(out + (size_t)kb * Z, xc, 4 * Z);
-    pack(xc, kb, 4);
+    if (words32) { // xc starts on a dword boundary
+        const uint32_t* x32 = reinterpret_cast<const uint32_t*>(xc);
+        for (int it = lane; it < 4 * W; it += 64) {
+            const int c = it / W, m = it - c * W;
+            const uint32_t* q = x32 + (c * Z + 32 * m) / 4;
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v |= squeeze(q[k]) << (4 * k);
+            put_word(kb + c, m, v);
+        }
+    } else {
+        pack(xc, kb, 4);
+    }
     wave_lds_sync();
     // 3c. extension rows
     const int next = nrows - 4;
