@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "nrldpc_kernels.h"
 
@@ -90,6 +91,77 @@ __global__ __launch_bounds__(256) void nrldpc_rate_recover_kernel(const RmArgs a
             }
             // (fillers inside the buffer: the reference keeps NaN there; the position is forced to +inf every time)
             o[t] = to_out<OutT>(filler ? __builtin_inff() : val);
+        }
+        if (vec) {
+            struct alignas(2 * sizeof(OutT)) Pair { OutT x, y; };
+            *reinterpret_cast<Pair*>(out + pos0) = Pair{o[0], o[1]};
+        } else {
+            out[pos0] = o[0];
+            if (pos0 + 1 < ncwz) out[pos0 + 1] = o[1];
+        }
+    }
+}
+
+// The same gather for the usual case -- no repetition (E_r <= non-filler positions of the buffer for every code block) --
+// with Q_m a template argument and no data-dependent branch: the general kernel above is 1259 instructions per wave and
+// 512 positions, most of them divergent control flow around the repetition walk, and runs at the rate it can issue them
+// (0.46 of the HBM roofline); this one computes both positions of a pair with selects and clamps the load index of a
+// position that receives nothing.  Same values: a position takes exactly one e(k) or none.
+template <typename OutT, int QM>
+__global__ __launch_bounds__(256) void nrldpc_rate_recover_fast_kernel(const RmArgs a) {
+    const int blk = blockIdx.y;
+    const int tb = blk / a.C, r = blk - tb * a.C;
+    const int ncwz = 2 * a.Z + a.N;
+    const int lane = threadIdx.x & 63;
+    const int tile0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RR_TILE;
+    if (tile0 >= ncwz) return;
+    const int lo_f = a.Kp - 2 * a.Z > 0 ? a.Kp - 2 * a.Z : 0, hi_f = a.K - 2 * a.Z;
+    const int f_hi = hi_f < a.N_cb ? hi_f : a.N_cb;
+    const int F = f_hi > lo_f ? f_hi - lo_f : 0;
+    const int P = a.N_cb - F;
+    int nfk0 = a.k0 - lo_f;
+    nfk0 = a.k0 - (nfk0 < 0 ? 0 : (nfk0 > F ? F : nfk0));
+    const int E = a.E[r];
+    const int rows = E > 0 ? E / QM : 1;
+    const float* f = a.g + (size_t)tb * a.G + a.off[r];
+    float* hb = a.harq ? a.harq + (size_t)blk * a.N_cb : nullptr;
+    OutT* out = static_cast<OutT*>(a.out) + (size_t)blk * ncwz;
+    const bool vec = (ncwz % 2) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+#pragma unroll
+    for (int s = 0; s < RR_PAIRS; ++s) {
+        const int pos0 = tile0 + s * 128 + 2 * lane;
+        if (pos0 >= ncwz) break;
+        float v[2];
+        bool fill[2], live[2];
+        int idx[2], pp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int p = pos0 + t - 2 * a.Z;
+            fill[t] = p >= lo_f && p < hi_f;
+            const bool inbuf = p >= 0 && p < a.N_cb && !fill[t];
+            int c = p - lo_f;
+            c = c < 0 ? 0 : (c > F ? F : c);
+            int q = p - c - nfk0;
+            q += q < 0 ? P : 0;
+            int i = 0;
+#pragma unroll
+            for (int m = 1; m < QM; ++m) i += (q >= m * rows);
+            const int j = q - i * rows;
+            live[t] = inbuf && q < E;
+            idx[t] = live[t] ? j * QM + i : 0;
+            pp[t] = inbuf ? p : -1;
+        }
+        v[0] = f[idx[0]];
+        v[1] = f[idx[1]];
+        OutT o[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float val = live[t] ? v[t] : 0.0f;
+            if (hb && pp[t] >= 0) { // :236-239
+                val += hb[pp[t]];
+                hb[pp[t]] = val;
+            }
+            o[t] = to_out<OutT>(fill[t] ? __builtin_inff() : val);
         }
         if (vec) {
             struct alignas(2 * sizeof(OutT)) Pair { OutT x, y; };
@@ -187,12 +259,35 @@ hipError_t launch_rate_match(const TxRmArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <typename OutT> static void launch_rr_fast(const RmArgs& a, dim3 grid, hipStream_t stream) {
+    switch (a.Qm) {
+        case 1: hipLaunchKernelGGL((nrldpc_rate_recover_fast_kernel<OutT, 1>), grid, dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((nrldpc_rate_recover_fast_kernel<OutT, 2>), grid, dim3(256), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((nrldpc_rate_recover_fast_kernel<OutT, 4>), grid, dim3(256), 0, stream, a); break;
+        case 6: hipLaunchKernelGGL((nrldpc_rate_recover_fast_kernel<OutT, 6>), grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL((nrldpc_rate_recover_fast_kernel<OutT, 8>), grid, dim3(256), 0, stream, a); break;
+    }
+}
+
 hipError_t launch_rate_recover(const RmArgs& a, hipStream_t stream) {
     const int ncwz = 2 * a.Z + a.N;
     const int per_block = 4 * RR_TILE;
     dim3 grid((ncwz + per_block - 1) / per_block, a.n_tb * a.C);
-    if (a.out_f16) hipLaunchKernelGGL(nrldpc_rate_recover_kernel<__half>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(nrldpc_rate_recover_kernel<float>, grid, dim3(256), 0, stream, a);
+    // non-filler positions of the circular buffer: a code block with more bits than that repeats (soft combining walk)
+    const int lo_f = a.Kp - 2 * a.Z > 0 ? a.Kp - 2 * a.Z : 0, hi_f = a.K - 2 * a.Z;
+    const int f_hi = hi_f < a.N_cb ? hi_f : a.N_cb;
+    const int P = a.N_cb - (f_hi > lo_f ? f_hi - lo_f : 0);
+    bool repeats = getenv("NRLDPC_RR_GENERAL") != nullptr; // A/B: force the general kernel
+    for (int r = 0; r < a.C; ++r) repeats = repeats || a.E[r] > P;
+    const bool qm_ok = a.Qm == 1 || a.Qm == 2 || a.Qm == 4 || a.Qm == 6 || a.Qm == 8;
+    if (!repeats && qm_ok) {
+        if (a.out_f16) launch_rr_fast<__half>(a, grid, stream);
+        else launch_rr_fast<float>(a, grid, stream);
+    } else if (a.out_f16) {
+        hipLaunchKernelGGL(nrldpc_rate_recover_kernel<__half>, grid, dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(nrldpc_rate_recover_kernel<float>, grid, dim3(256), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
