@@ -222,6 +222,7 @@ def main():
     args = ap.parse_args()
 
     import torch
+    torch.set_num_threads(4)  # host-side tensor copies only; idle OpenMP workers would spend the container's CPU quota
     if args.dry_run:
         return dry_run(args, torch)
     if not torch.cuda.is_available():
