@@ -71,20 +71,14 @@ template <int NB> __device__ __forceinline__ void rail_llr(float y, float inv_n0
     for (int k = 0; k < NB; ++k) llr[k] = (mx[k][0] + logf(sm[k][0])) - (mx[k][1] + logf(sm[k][1]));
 }
 
-template <int QM> __global__ __launch_bounds__(256) void nrldpc_awgn_llr_kernel(const ChanArgs a) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // symbol of this launch
-    if (s >= a.n_sym) return;
-    const uint64_t gs = a.first_symbol + (uint64_t)s;
-    uint32_t r[4];
-    philox4x32_10((uint32_t)gs, (uint32_t)(gs >> 32), 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+// LLRs of one symbol from its bits and the two uniform words of its noise sample
+template <int QM> __device__ __forceinline__ void symbol_llr(const ChanArgs& a, const uint8_t* g, uint32_t w1, uint32_t w2, float* o) {
     // Box-Muller on 24-bit uniforms in (0,1): exact in f32
-    const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u1 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = ((float)(w2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float rad = sqrtf(-2.0f * logf(u1)) * a.sigma; // sigma = sqrt(N0/2) per rail
     float sn, cs;
     sincosf(6.283185307179586f * u2, &sn, &cs);
     const float ni = rad * cs, nq = rad * sn;
-    const uint8_t* g = a.g + s * QM;
-    float* o = a.llr + s * QM;
     if constexpr (QM == 1) { // comm.PSKModulator order 2, phase offset pi/4 (NRModulator.m:73): LLR = 4 Re(rx e^{-j pi/4}) / N0
         const float tx = (g[0] & 1u) ? -1.0f : 1.0f;
         const float y = tx + (ni + nq) * 0.70710678118654752f; // noise projected onto the signalling axis
@@ -103,8 +97,47 @@ template <int QM> __global__ __launch_bounds__(256) void nrldpc_awgn_llr_kernel(
     }
 }
 
+// A thread owns the pair of symbols (2c, 2c+1) of the global symbol count: one Philox call -- counter c, four words -- feeds
+// both (words 0,1 the even symbol, words 2,3 the odd one); a generator call per symbol threw half of its output away and was
+// what the kernel spent most of its instructions on.  Pairs are aligned to the global count, so the noise of a symbol does not
+// depend on how the symbols are split over launches.
+template <int QM> __global__ __launch_bounds__(256) void nrldpc_awgn_llr_kernel(const ChanArgs a) {
+    const uint64_t c = (a.first_symbol >> 1) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // pair index = Philox counter
+    const int64_t s0 = (int64_t)(2 * c - a.first_symbol);                                        // local index of the even symbol
+    if (s0 >= a.n_sym) return;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+    const bool v0 = s0 >= 0, v1 = s0 + 1 < a.n_sym;
+    float o[2 * QM];
+    uint8_t bits[2 * QM];
+    const uint8_t* g = a.g + s0 * QM;
+    float* dst = a.llr + s0 * QM;
+    const bool both = v0 && v1;
+    if (QM == 2 && both && (reinterpret_cast<uintptr_t>(g) & 3) == 0) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bits[k < 2 * QM ? k : 0] = (uint8_t)(w >> (8 * k));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2 * QM; ++k) bits[k] = ((k < QM ? v0 : v1) ? g[k] : (uint8_t)0);
+    }
+    symbol_llr<QM>(a, bits, r[0], r[1], o);
+    symbol_llr<QM>(a, bits + QM, r[2], r[3], o + QM);
+    if (QM == 2 && both && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[QM < 2 ? 0 : 2], o[QM < 2 ? 0 : 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < QM; ++k) {
+            if (v0) dst[k] = o[k];
+            if (v1) dst[QM + k] = o[QM + k];
+        }
+    }
+}
+
 hipError_t launch_awgn_llr(const ChanArgs& a, hipStream_t stream) {
-    const dim3 grid((unsigned)((a.n_sym + 255) / 256)), block(256);
+    // pairs of the global symbol count that the launch touches
+    const uint64_t npairs = ((a.first_symbol + (uint64_t)a.n_sym - 1) >> 1) - (a.first_symbol >> 1) + 1;
+    const dim3 grid((unsigned)((npairs + 255) / 256)), block(256);
     switch (a.Qm) {
         case 1: hipLaunchKernelGGL(nrldpc_awgn_llr_kernel<1>, grid, block, 0, stream, a); break;
         case 2: hipLaunchKernelGGL(nrldpc_awgn_llr_kernel<2>, grid, block, 0, stream, a); break;

@@ -2,7 +2,8 @@
 
 numpy restatement, in float64, of what the kernel computes: NRModulator.m:73-81 (TS 38.211 5.1 maps, unit average
 power), complex AWGN of variance N0 = 10^(-EsN0/10) (plot_BLER_vs_SNR.m:50,105-106) drawn from Philox-4x32-10
-(counter = global symbol index, key = seed) through Box-Muller on 24-bit uniforms, and NRDemodulator.m:76-84's exact
+(counter = global symbol index div 2, key = seed; words 0,1 of the block feed the even symbol of the pair, words 2,3 the
+odd one) through Box-Muller on 24-bit uniforms, and NRDemodulator.m:76-84's exact
 log-likelihood ratios.  The kernel works in float32 with the device's logf / sincosf / expf, so tests compare within a
 stated tolerance, not bit for bit.  Only tests/ may import this module.
 """
@@ -35,9 +36,13 @@ def philox4x32_10(counter_lo, counter_hi, seed):
 def noise(n_sym, seed, first_symbol, N0):
     """Complex noise of variance N0 for symbols first_symbol .. first_symbol + n_sym - 1."""
     s = np.uint64(first_symbol) + np.arange(n_sym, dtype=np.uint64)
-    r = philox4x32_10(s & M32, s >> np.uint64(32), int(seed))
-    u1 = ((r[:, 0] >> 8).astype(np.float64) + 0.5) / 16777216.0
-    u2 = ((r[:, 1] >> 8).astype(np.float64) + 0.5) / 16777216.0
+    c = s >> np.uint64(1)
+    r = philox4x32_10(c & M32, c >> np.uint64(32), int(seed))
+    odd = (s & np.uint64(1)).astype(bool)
+    w1 = np.where(odd, r[:, 2], r[:, 0])
+    w2 = np.where(odd, r[:, 3], r[:, 1])
+    u1 = ((w1 >> 8).astype(np.float64) + 0.5) / 16777216.0
+    u2 = ((w2 >> 8).astype(np.float64) + 0.5) / 16777216.0
     rad = np.sqrt(-2.0 * np.log(u1)) * np.sqrt(N0 / 2.0)
     ang = 2.0 * np.pi * u2
     return rad * np.cos(ang) + 1j * rad * np.sin(ang)
