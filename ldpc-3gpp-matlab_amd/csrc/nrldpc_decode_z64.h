@@ -365,6 +365,17 @@ __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uin
     }
 }
 
+// Wave priority inside the software pipeline.  Between two barriers a wave first finishes its group (late reads, min search
+// over them, pass 2, LDS writes: what every other wave of the workgroup waits for at the next barrier) and then runs the
+// early part of the next group (work that merely has to be done some time before that group's own barrier).  With equal
+// priorities the SIMD's arbiter lets a wave that is already in the second part take issue slots from a sibling that is
+// still in the first, and the barrier opens later.  s_setprio 2 for the first part, 0 for the second: the headline launch
+// went from 3.96 to 3.67 ms (8.7 -> 9.4 Gbit/s; levels 1, 2, 3 and a window that starts at pass 2 measure the same).
+// -DNRLDPC_Z64_PRIO=0 builds the kernel without the effect (A/B).
+#ifndef NRLDPC_Z64_PRIO
+#define NRLDPC_Z64_PRIO 2
+#endif
+
 // ---- software pipeline over barrier groups (FULL && PLAIN kernels) -------------------------------------
 // Group gi's layers; `early` = loads + min search over the edges that do not depend on the previous group.
 template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS> struct GroupZ64 {
@@ -419,6 +430,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
                                              uint32_t& esign_hi) {
     constexpr int NG = LayerGroups<BG, NL>::ngroups();
     __syncthreads(); // ends group GI-1 (for GI == 0: the previous iteration / the prologue)
+    __builtin_amdgcn_s_setprio(NRLDPC_Z64_PRIO); // urgent until this group's writes are out (see NRLDPC_Z64_PRIO)
     cur.template loads<true>(lds, R);
     if constexpr (GI + 1 < NG) {
         GroupZ64<BG, ZC, GI + 1, NL> nxt;
@@ -426,6 +438,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
         cur.template track<true>(st, cap);
         cur.finish(st, lds, R, a);
         cur.twins(lds, RA, RB, w);
+        __builtin_amdgcn_s_setprio(0); // the next group's early part only fills gaps
         if constexpr (ET) {
             cur.ext(a, esign_lo, esign_hi);
             // pin the bits here: their only reader is the parity pass, and LLVM otherwise sinks all 42 rows'
@@ -439,6 +452,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
         cur.template track<true>(st, cap);
         cur.finish(st, lds, R, a);
         cur.twins(lds, RA, RB, w);
+        __builtin_amdgcn_s_setprio(0); // the next group's early part only fills gaps
         if constexpr (ET) {
             cur.ext(a, esign_lo, esign_hi);
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
