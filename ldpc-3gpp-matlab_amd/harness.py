@@ -128,7 +128,7 @@ def simulate_point_device(enc_chain, dec_chain, Q_m, EsN0, rv_id_sequence, batch
     ok = torch.zeros(batch, dtype=torch.bool, device=dev)
     a_hat = torch.zeros((batch, p.A), dtype=torch.uint8, device=dev)
     dec_chain.reset()                                                                      # :122
-    for rv in rv_id_sequence:                                                              # :124-137
+    for n_rv, rv in enumerate(rv_id_sequence):                                             # :124-137
         p.rv_id = rv
         g = enc_chain.step(a)
         if chan is not None:                                                               # :130-132 in one kernel
@@ -145,9 +145,9 @@ def simulate_point_device(enc_chain, dec_chain, Q_m, EsN0, rv_id_sequence, batch
             g_tilde = demodulate_llr_t(tx + noise, Q_m, N0).float()
         dec, good, _ = dec_chain.step(g_tilde)
         newly = good & ~ok
-        a_hat[newly] = dec[newly]
+        a_hat = torch.where(newly[:, None], dec, a_hat)  # (no boolean indexing: that is a host synchronisation per batch)
         ok |= good
-        if bool(ok.all()):
+        if n_rv + 1 < len(rv_id_sequence) and bool(ok.all()):  # the reference stops retransmitting once the block is in (:136)
             break
     return (ok & (a_hat == a).all(dim=1)).cpu().numpy()
 
