@@ -50,7 +50,13 @@ extern "C" {
 
 typedef struct nrldpc_codec* nrldpc_handle;
 
+/* ABI revision of this header.  Revision 3 put `struct_size` in front of nrldpc_cfg and nrldpc_dims (revision 2 had
+ * grown both at the tail -- beta; alpha, beta -- with nothing a caller built against revision 1 could be told apart by).
+ * nrldpc_abi_version() returns the revision the loaded library was built with; the library's SONAME carries it too. */
+#define NRLDPC_ABI_VERSION 3
+
 typedef struct nrldpc_cfg {
+    uint32_t struct_size; /* = sizeof(nrldpc_cfg); nrldpc_create refuses any other value (NRLDPC_ERR_ARG)      */
     int32_t bg;         /* 1 or 2                                     (NRLDPC.m:28)               */
     int32_t Z;          /* lifting size Z_c, one of the 51 of Table 5.3.2-1 (NRLDPC.m:409-411)    */
     int32_t n_layers;   /* base rows to decode, 4..46 (BG1) / 4..42 (BG2); 0 = all (reference: all) */
@@ -69,6 +75,7 @@ typedef struct nrldpc_cfg {
 
 /* Dimensions implied by (bg, Z): ncols*Z LLRs in, K = kb*Z hard bits out. */
 typedef struct nrldpc_dims {
+    uint32_t struct_size;     /* in: = sizeof(nrldpc_dims), set by the caller before nrldpc_get_dims */
     int32_t nrows, ncols, kb; /* 46,68,22 or 42,52,10 */
     int32_t i_ls;             /* set index (get_3gpp_set_index.m) */
     int32_t K, N_cw;          /* kb*Z, ncols*Z */
@@ -76,6 +83,7 @@ typedef struct nrldpc_dims {
     float alpha, beta;        /* resolved check-node rule (beta in LLR units) */
 } nrldpc_dims;
 
+int nrldpc_abi_version(void); /* NRLDPC_ABI_VERSION of the library's build */
 int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out);
 void nrldpc_destroy(nrldpc_handle h);
 int nrldpc_get_dims(nrldpc_handle h, nrldpc_dims* out);
@@ -99,7 +107,8 @@ int nrldpc_quantise_llr(int8_t* dst, const void* src, int64_t n, int32_t llr_dty
  * count, iteration cap, ...) decoded with one launch per base graph and LLR type instead of n launches --
  * a small bucket alone is a one-workgroup kernel that leaves the GPU idle.  For i < n: batch[i] codewords at
  * d_llr[i] (dtype of h[i]) -> d_hard[i], iteration counts to d_iters[i] when d_iters and d_iters[i] are
- * non-null.  Results are those of n nrldpc_decode_dev calls.  Tables are staged in h[0]; asynchronous on
+ * non-null.  Results are those of n nrldpc_decode_dev calls.  The launch tables go through a ring of four
+ * (pinned, device, event) slots owned by h[0], so calls in flight on different streams never share one; asynchronous on
  * `stream`.  (The reference decodes one code block per step(), NRLDPCDecoder.m:257-266; a receiver serving many
  * users holds exactly such a mix of (BG, Z_c).) */
 int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* h, const void* const* d_llr, const int32_t* batch,
@@ -115,6 +124,14 @@ typedef struct nrldpc_pool* nrldpc_pool_handle;
 int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t n_devices, int32_t chunks_per_device,
                        nrldpc_pool_handle* out);
 int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out);
+/* The same for data that is already ON the devices: shard i (entry i of device_ids) decodes batch[i] codewords from
+ * d_llr[i] into d_hard[i] (and d_iters[i] when d_iters and d_iters[i] are non-null); every pointer of shard i is
+ * device memory of device_ids[i], in cfg.llr_dtype (F32 / F16).  One host thread per shard launches on the shard's
+ * own stream; the call returns when every shard's stream is idle.  No host copy, no collective: this is the form that
+ * scales with the number of GPUs (the host-pointer form above is bounded by the host's copy bandwidth). */
+int nrldpc_pool_decode_dev(nrldpc_pool_handle p, const void* const* d_llr, const int32_t* batch, uint8_t* const* d_hard,
+                           int32_t* const* d_iters);
+int nrldpc_pool_size(nrldpc_pool_handle p); /* number of shards (n_devices of nrldpc_pool_create) */
 /* codewords each shard (entry of device_ids) decoded in the last nrldpc_pool_decode call; counts: [n_devices] */
 int nrldpc_pool_last_split(nrldpc_pool_handle p, int32_t* counts);
 void nrldpc_pool_destroy(nrldpc_pool_handle p);

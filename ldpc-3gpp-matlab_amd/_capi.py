@@ -25,14 +25,25 @@ class NRLDPCError(RuntimeError):
     identifier = "ldpc_3gpp_matlab:Error"
 
 
+ABI_VERSION = 3  # NRLDPC_ABI_VERSION of include/nrldpc.h
+
+
 class Cfg(C.Structure):
-    _fields_ = [("bg", C.c_int32), ("Z", C.c_int32), ("n_layers", C.c_int32), ("max_iter", C.c_int32),
+    """nrldpc_cfg; struct_size is filled in by the constructor (positional arguments start at bg)."""
+    _fields_ = [("struct_size", C.c_uint32), ("bg", C.c_int32), ("Z", C.c_int32), ("n_layers", C.c_int32), ("max_iter", C.c_int32),
                 ("early_term", C.c_int32), ("alpha", C.c_float), ("llr_scale", C.c_int32),
                 ("llr_dtype", C.c_int32), ("device_id", C.c_int32), ("max_batch", C.c_int32), ("beta", C.c_float)]
 
 
+def _cfg_init(self, *args, **kw):
+    C.Structure.__init__(self, C.sizeof(Cfg), *args, **kw)
+
+
+Cfg.__init__ = _cfg_init
+
+
 class Dims(C.Structure):
-    _fields_ = [("nrows", C.c_int32), ("ncols", C.c_int32), ("kb", C.c_int32), ("i_ls", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("nrows", C.c_int32), ("ncols", C.c_int32), ("kb", C.c_int32), ("i_ls", C.c_int32),
                 ("K", C.c_int32), ("N_cw", C.c_int32), ("n_layers", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float)]
 
 
@@ -61,7 +72,7 @@ EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev", "nrldpc_crc_check_d
            "nrldpc_decode_multi_dev", "nrldpc_quantise_llr", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version", "nrldpc_build_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
-           "nrldpc_pool_destroy"]
+           "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version"]
 
 _lib = None
 
@@ -120,6 +131,10 @@ def load():
     L.nrldpc_pool_create.argtypes = [C.POINTER(Cfg), C.POINTER(i32), i32, i32, C.POINTER(vp)]
     L.nrldpc_pool_decode.argtypes = [vp, vp, i32, vp, vp]
     L.nrldpc_pool_last_split.argtypes = [vp, C.POINTER(i32)]
+    L.nrldpc_pool_decode_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp)]
+    L.nrldpc_pool_size.argtypes = [vp]
+    if L.nrldpc_abi_version() != ABI_VERSION:
+        raise RuntimeError("libnrldpc_hip.so speaks ABI revision %d, this binding %d" % (L.nrldpc_abi_version(), ABI_VERSION))
     L.nrldpc_pool_destroy.argtypes = [vp]
     L.nrldpc_pool_destroy.restype = None
     L.nrldpc_set_timing.argtypes = [vp, i32]
@@ -170,7 +185,7 @@ class Codec:
         cfg = Cfg(int(bg), int(Z), int(n_layers), int(max_iter), int(bool(early_term)), float(alpha),
                   int(llr_scale), _NP2DT[self.llr_dtype], int(device_id), int(max_batch), float(beta))
         check(L.nrldpc_create(C.byref(cfg), C.byref(self._h)))
-        d = Dims()
+        d = Dims(C.sizeof(Dims))
         check(L.nrldpc_get_dims(self._h, C.byref(d)))
         self.bg, self.Z = int(bg), int(Z)
         self.K, self.N_cw, self.kb, self.ncols, self.nrows = d.K, d.N_cw, d.kb, d.ncols, d.nrows
@@ -259,6 +274,19 @@ class CodecPool:
         iters = np.empty(B, np.int32) if want_iters else None
         check(self._lib.nrldpc_pool_decode(self._p, _ptr(llr), B, _ptr(hard), _ptr(iters)))
         return (hard, iters) if want_iters else hard
+
+    def decode_dev(self, d_llr, batch, d_hard, d_iters=None):
+        """nrldpc_pool_decode_dev: shard i decodes batch[i] codewords at device address d_llr[i] (memory of
+        device_ids[i]) into d_hard[i]; returns when every shard's stream is idle.  No host copies."""
+        n = len(self.device_ids)
+        if not (len(d_llr) == len(batch) == len(d_hard) == n):
+            raise NRLDPCError("one entry per shard expected")
+        vp = C.c_void_p
+        a_llr = (vp * n)(*[vp(int(x)) for x in d_llr])
+        a_hard = (vp * n)(*[vp(int(x)) for x in d_hard])
+        a_b = (C.c_int32 * n)(*[int(b) for b in batch])
+        a_it = (vp * n)(*[vp(int(x) if x else None) for x in d_iters]) if d_iters is not None else None
+        check(self._lib.nrldpc_pool_decode_dev(self._p, a_llr, a_b, a_hard, a_it))
 
     def last_split(self):
         """Codewords each shard decoded in the last call (uneven under early termination: faster shards pull more)."""

@@ -207,9 +207,13 @@ class HostPool {
 
 public:
     std::vector<cpu_set_t> nodes_;
+    cpu_set_t proc_mask_; // affinity of the creating thread = what the host process allows
     int node_ = -1;
 
     explicit HostPool(int n) {
+        CPU_ZERO(&proc_mask_);
+        if (sched_getaffinity(0, sizeof(cpu_set_t), &proc_mask_) != 0)
+            for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &proc_mask_);
         if (getenv("NRLDPC_HOST_NO_PIN") == nullptr) (void)numa_cpus(&nodes_);
         for (int i = 0; i < n; ++i)
             th_.emplace_back([this, i, n] {
@@ -249,8 +253,13 @@ public:
         if (nodes_.size() < 2) return;
         const int node = numa_node_of(p, bytes);
         if (node < 0 || node >= (int)nodes_.size() || node == node_) return;
-        for (auto& t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(cpu_set_t), &nodes_[node]);
+        // never widen what the host process was started with (taskset / numactl / a MATLAB worker's mask): the workers
+        // move to the node's CPUs that the process itself may run on, and stay where they are when there is none
+        cpu_set_t want;
+        CPU_AND(&want, &nodes_[node], &proc_mask_);
         node_ = node;
+        if (CPU_COUNT(&want) == 0) return;
+        for (auto& t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(cpu_set_t), &want);
     }
     // f(worker, nworkers) on every worker; returns when all are done
     void run(std::function<void(int, int)> f) {
@@ -467,7 +476,8 @@ const char* nrldpc_strerror(int code) {
     }
 }
 const char* nrldpc_last_error(void) { return g_err.c_str(); }
-const char* nrldpc_version(void) { return "nrldpc-hip 0.2 (gfx950)"; }
+const char* nrldpc_version(void) { return "nrldpc-hip 0.3 (gfx950)"; }
+int nrldpc_abi_version(void) { return NRLDPC_ABI_VERSION; }
 #ifndef NRLDPC_BUILD_ID
 #define NRLDPC_BUILD_ID "unknown"
 #endif
@@ -485,10 +495,15 @@ int nrldpc_default_rule(int32_t bg, int32_t n_layers, float* alpha, float* beta)
     return NRLDPC_OK;
 }
 
-int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out) {
+int nrldpc_create(const nrldpc_cfg* cfg_in, nrldpc_handle* out) {
     NRLDPC_API_BEGIN
-    if (!cfg || !out) return fail(NRLDPC_ERR_ARG, "null cfg/out");
+    if (!cfg_in || !out) return fail(NRLDPC_ERR_ARG, "null cfg/out");
     *out = nullptr;
+    // struct_size is the caller's sizeof(nrldpc_cfg): a caller built against another revision of the header is refused
+    // instead of having fields read past the end of its struct
+    if (cfg_in->struct_size != (uint32_t)sizeof(nrldpc_cfg))
+        return fail(NRLDPC_ERR_ARG, "nrldpc_cfg.struct_size does not match this library (set it to sizeof(nrldpc_cfg); ABI revision mismatch?)");
+    const nrldpc_cfg* cfg = cfg_in;
     if (cfg->bg != 1 && cfg->bg != 2) return fail(NRLDPC_ERR_UNSUPPORTED, "BG must be 1 or 2");
     if (nrldpc::set_index(cfg->Z) < 0) return fail(NRLDPC_ERR_UNSUPPORTED, "Invalid lifting size.");
     if (cfg->max_iter < 1 || cfg->max_iter > 2000) return fail(NRLDPC_ERR_UNSUPPORTED, "max_iter must be in 1..2000");
@@ -583,6 +598,8 @@ void nrldpc_destroy(nrldpc_handle h) {
 
 int nrldpc_get_dims(nrldpc_handle h, nrldpc_dims* out) {
     if (!h || !out) return fail(NRLDPC_ERR_ARG, "null handle/out");
+    if (out->struct_size != (uint32_t)sizeof(nrldpc_dims))
+        return fail(NRLDPC_ERR_ARG, "nrldpc_dims.struct_size does not match this library (set it to sizeof(nrldpc_dims) before the call)");
     const nrldpc::Schedule& s = h->sched;
     out->nrows = s.g.nrows; out->ncols = s.g.ncols; out->kb = s.g.kb; out->i_ls = s.ils;
     out->K = s.g.kb * s.Z; out->N_cw = s.g.ncols * s.Z; out->n_layers = s.n_layers;
@@ -886,6 +903,22 @@ struct nrldpc_pool {
     const char* llr = nullptr; uint8_t* hard = nullptr; int32_t* iters = nullptr;
     int batch = 0, chunk = 0, nchunks = 0, next = 0, running = 0, rc = NRLDPC_OK;
     std::string err;
+    // device-resident job (nrldpc_pool_decode_dev): shard i launches on its own stream and waits for it
+    bool dev_job = false;
+    const void* const* dv_llr = nullptr; const int32_t* dv_batch = nullptr; uint8_t* const* dv_hard = nullptr;
+    int32_t* const* dv_iters = nullptr;
+    std::vector<hipStream_t> streams;
+
+    int decode_dev_shard(int i) {
+        if (dv_batch[i] <= 0) return dv_batch[i] < 0 ? fail(NRLDPC_ERR_ARG, "negative batch") : NRLDPC_OK;
+        nrldpc_handle h = hs[i];
+        DEVICE_SCOPE(h);
+        if (!streams[i]) HIP_TRY(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));
+        const int r = nrldpc_decode_dev(h, dv_llr[i], dv_batch[i], dv_hard[i], dv_iters ? dv_iters[i] : nullptr, nullptr, streams[i]);
+        if (r != NRLDPC_OK) return r;
+        HIP_TRY(hipStreamSynchronize(streams[i]));
+        return NRLDPC_OK;
+    }
 
     void worker(int i) {
         unsigned seen = 0;
@@ -896,7 +929,12 @@ struct nrldpc_pool {
                 if (stop) return;
                 seen = gen;
             }
-            for (;;) {
+            if (dev_job) {
+                const int r = decode_dev_shard(i);
+                std::lock_guard<std::mutex> lk(m);
+                if (r != NRLDPC_OK && rc == NRLDPC_OK) { rc = r; err = nrldpc_last_error(); }
+                split[i] = dv_batch[i] > 0 ? dv_batch[i] : 0;
+            } else for (;;) {
                 int k;
                 {
                     std::lock_guard<std::mutex> lk(m);
@@ -944,6 +982,7 @@ int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t
     p->ncw = (size_t)s.g.ncols * s.Z; p->K = (size_t)s.g.kb * s.Z;
     p->eb = cfg->llr_dtype == NRLDPC_LLR_F64 ? 8 : cfg->llr_dtype == NRLDPC_LLR_F16 ? 2 : 4; // in the caller's array
     p->split.assign(n_devices, 0);
+    p->streams.assign(n_devices, nullptr);
     for (int i = 0; i < n_devices; ++i) p->th.emplace_back([p, i] { p->worker(i); });
     *out = p;
     return NRLDPC_OK;
@@ -962,6 +1001,7 @@ int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uin
     p->nchunks = (batch + p->chunk - 1) / p->chunk;
     p->llr = static_cast<const char*>(llr); p->hard = hard; p->iters = iters_out; p->batch = batch;
     p->next = 0; p->rc = NRLDPC_OK; p->err.clear();
+    p->dev_job = false;
     std::fill(p->split.begin(), p->split.end(), 0);
     p->running = (int)p->th.size();
     ++p->gen;
@@ -971,6 +1011,30 @@ int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uin
     return NRLDPC_OK;
     NRLDPC_API_END
 }
+
+int nrldpc_pool_decode_dev(nrldpc_pool_handle p, const void* const* d_llr, const int32_t* batch, uint8_t* const* d_hard,
+                           int32_t* const* d_iters) {
+    NRLDPC_API_BEGIN
+    if (!p) return fail(NRLDPC_ERR_ARG, "null pool");
+    if (!d_llr || !batch || !d_hard) return fail(NRLDPC_ERR_ARG, "null d_llr/batch/d_hard array");
+    for (size_t i = 0; i < p->hs.size(); ++i)
+        if (batch[i] > 0 && (!d_llr[i] || !d_hard[i])) return fail(NRLDPC_ERR_ARG, "null device pointer for a shard with work");
+    std::unique_lock<std::mutex> lk(p->m);
+    p->dev_job = true;
+    p->dv_llr = d_llr; p->dv_batch = batch; p->dv_hard = d_hard; p->dv_iters = d_iters;
+    p->rc = NRLDPC_OK; p->err.clear();
+    std::fill(p->split.begin(), p->split.end(), 0);
+    p->running = (int)p->th.size();
+    ++p->gen;
+    p->cv.notify_all();
+    p->cv_done.wait(lk, [&] { return p->running == 0; });
+    p->dev_job = false;
+    if (p->rc != NRLDPC_OK) return fail(p->rc, p->err);
+    return NRLDPC_OK;
+    NRLDPC_API_END
+}
+
+int nrldpc_pool_size(nrldpc_pool_handle p) { return p ? (int)p->hs.size() : 0; }
 
 int nrldpc_pool_last_split(nrldpc_pool_handle p, int32_t* counts) {
     if (!p || !counts) return fail(NRLDPC_ERR_ARG, "null pool/counts");
@@ -987,6 +1051,8 @@ void nrldpc_pool_destroy(nrldpc_pool_handle p) {
     }
     p->cv.notify_all();
     for (auto& t : p->th) t.join();
+    for (size_t i = 0; i < p->hs.size(); ++i)
+        if (p->streams[i]) { DeviceScope scope(p->hs[i]->cfg.device_id); (void)hipStreamDestroy(p->streams[i]); }
     for (auto h : p->hs) nrldpc_destroy(h);
     delete p;
 }

@@ -27,6 +27,17 @@
 #define NRLDPC_DECODE_Z64_H
 #include "nrldpc_device.h"
 
+// scheduling experiments of the software pipeline (see pipeline_z64 / LayerZ64::track3); 0 = the shipped schedule
+#ifndef NRLDPC_Z64_POSTBAR
+#define NRLDPC_Z64_POSTBAR 0
+#endif
+#ifndef NRLDPC_Z64_DEFER
+#define NRLDPC_Z64_DEFER 0
+#endif
+#ifndef NRLDPC_Z64_DEFER_EXT
+#define NRLDPC_Z64_DEFER_EXT 0
+#endif
+
 namespace nrldpc {
 
 constexpr int z64_set_index(int Z) {
@@ -149,13 +160,14 @@ template <int LO, int HI, class F> __device__ __forceinline__ void dispatch_w(in
 
 // One base-graph layer for this thread's check row, split into phases so that the layers of a
 // column-disjoint barrier group can issue all their LDS reads first and share one mirror dispatch.
-template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct LayerZ64 {
+template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> struct LayerZ64 {
     using G = Z64<BG, ZC, z64_ncwg<BG, ZC>(), NL>;
     static constexpr int e0 = G::row_ptr(L);
     static constexpr int deg = G::row_ptr(L + 1) - e0;
     static constexpr bool HAS_EXT = (L >= 4);
     static constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
-    static constexpr int ce0 = G::core_base(L);
+    static constexpr int ce0 = Own<BG, NL, H>::core_base(L); // first message byte of this layer in the thread's store
+    static constexpr int XI = HAS_EXT ? Own<BG, NL, H>::ext_index(L) : 0; // its extension LLR there
     float t[ncore];
     float lam, m1, M1, M2;
 
@@ -194,27 +206,40 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct Layer
         for (int i = 0; i < j; ++i) n += (is_late(i) == LATE);
         return n;
     }
-    template <bool LATE, bool XF = false> __device__ __forceinline__ void track_part(const DecState<BG>& st, float cap) {
+    // Early edges whose min search is DEFERRED until after the barrier (their LDS reads still precede it): the first
+    // NRLDPC_Z64_DEFER early edges of a layer (and, with NRLDPC_Z64_DEFER_EXT, its thread-private extension bit).  Every
+    // wave of a SIMD leaves a barrier at the same moment and then waits one LDS round trip for its late reads; the
+    // deferred edges are work that is ready to issue in that shadow.  min / med3 / xor are order-independent on exact
+    // integers, so results do not depend on the split.
+    static constexpr bool is_deferred(int j) { return !is_late(j) && part_count_before<false>(j) < NRLDPC_Z64_DEFER; }
+    // PART 0: early, tracked before the barrier (starts the search); 1: early, deferred; 2: late
+    static constexpr int part_of(int j) { return is_late(j) ? 2 : is_deferred(j) ? 1 : 0; }
+    template <int PART> static constexpr int pcount_before(int j) {
+        int n = 0;
+        for (int i = 0; i < j; ++i) n += (part_of(i) == PART);
+        return n;
+    }
+    template <int PART, bool XF = false, class St> __device__ __forceinline__ void track3(const St& st, float cap) {
         // cap = (127.49 + beta)/alpha: the search starts from it, so alpha*m - beta never rounds above 127 and needs no upper clamp
-        if constexpr (!LATE) { pm1 = cap; pm2 = cap; pS = 0; }
+        if constexpr (PART == 0) { pm1 = cap; pm2 = cap; pS = 0; }
         uint32_t pend = 0;
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if constexpr (LayerZ64::is_late(j) == LATE) {
+            if constexpr (LayerZ64::part_of(j) == PART) {
                 constexpr int ce = ce0 + j;
                 const float tj = t[j] - byte_to_f32<ce & 3>(st.rm[ce >> 2]);
                 t[j] = tj;
                 const float aj = fabsf(tj);
                 pm2 = __builtin_amdgcn_fmed3f(aj, pm1, pm2);
                 pm1 = fminf(pm1, aj);
-                if constexpr (LayerZ64::template part_count_before<LATE>(j) % 2 == 0) pend = fbits(tj);
+                if constexpr (LayerZ64::template pcount_before<PART>(j) % 2 == 0) pend = fbits(tj);
                 else pS = __builtin_amdgcn_bitop3_b32(pS, pend, fbits(tj), 0x96);
             }
         });
-        constexpr int npart = part_count_before<LATE>(ncore);
-        if constexpr (!LATE && HAS_EXT) { // the extension bit is thread-private: always "early"
-            if constexpr (XF) lam = st.xf[L - 4];
-            else lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
+        constexpr int npart = pcount_before<PART>(ncore);
+        if constexpr (PART == (NRLDPC_Z64_DEFER_EXT ? 1 : 0) && HAS_EXT) { // the extension bit is thread-private: never "late"
+            if constexpr (XF) lam = st.xf[XI];
+            else lam = byte_to_f32<XI & 3>(st.xq[XI >> 2]);
             const float al = fabsf(lam);
             pm2 = __builtin_amdgcn_fmed3f(al, pm1, pm2);
             pm1 = fminf(pm1, al);
@@ -224,8 +249,16 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct Layer
             if constexpr (npart % 2 == 1) pS ^= pend;
         }
     }
+    template <bool LATE, bool XF = false, class St> __device__ __forceinline__ void track_part(const St& st, float cap) {
+        if constexpr (LATE) {
+            if constexpr (NRLDPC_Z64_DEFER > 0 || NRLDPC_Z64_DEFER_EXT) track3<1, XF>(st, cap);
+            track3<2, XF>(st, cap);
+        } else {
+            track3<0, XF>(st, cap);
+        }
+    }
     // pass 2 for all edges after both parts have been tracked
-    __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
+    template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         m1 = pm1;
         // magnitudes carrying the row's sign parity: M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
         // a.beta holds 2^23 - beta here (set up by the pipelined kernels, see scale_mag_magic)
@@ -266,7 +299,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS> struct Layer
         });
         lam = 0.0f;
         if constexpr (HAS_EXT) {
-            lam = byte_to_f32<(L - 4) & 3>(st.xq[(L - 4) >> 2]);
+            lam = byte_to_f32<XI & 3>(st.xq[XI >> 2]);
             const float al = fabsf(lam);
             mm2 = __builtin_amdgcn_fmed3f(al, mm1, mm2);
             mm1 = fminf(mm1, al);
@@ -378,27 +411,27 @@ __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uin
 
 // ---- software pipeline over barrier groups (FULL && PLAIN kernels) -------------------------------------
 // Group gi's layers; `early` = loads + min search over the edges that do not depend on the previous group.
-template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS> struct GroupZ64 {
+template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct GroupZ64 {
     using LG = LayerGroups<BG, NL>;
     static constexpr int GS = LG::group_first(GI);
     static constexpr int N = LG::group_last(GS) - GS + 1;
     static_assert(N >= 1 && N <= 3, "group size");
     struct NoLayer {}; // absent second / third layer: no storage, so copying a group copies only live state
-    LayerZ64<BG, ZC, GS, true, NL> l0;
-    std::conditional_t<(N > 1), LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true, NL>, NoLayer> l1;
-    std::conditional_t<(N > 2), LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true, NL>, NoLayer> l2;
+    LayerZ64<BG, ZC, GS, true, NL, H> l0;
+    std::conditional_t<(N > 1), LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true, NL, H>, NoLayer> l1;
+    std::conditional_t<(N > 2), LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true, NL, H>, NoLayer> l2;
 
     template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
         l0.template load_part<LATE>(lds, R);
         if constexpr (N > 1) l1.template load_part<LATE>(lds, R);
         if constexpr (N > 2) l2.template load_part<LATE>(lds, R);
     }
-    template <bool LATE, bool XF = false> __device__ __forceinline__ void track(const DecState<BG>& st, float cap) {
+    template <bool LATE, bool XF = false, class St> __device__ __forceinline__ void track(const St& st, float cap) {
         l0.template track_part<LATE, XF>(st, cap);
         if constexpr (N > 1) l1.template track_part<LATE, XF>(st, cap);
         if constexpr (N > 2) l2.template track_part<LATE, XF>(st, cap);
     }
-    __device__ __forceinline__ void finish(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
+    template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         l0.finish(st, lds, R, a);
         if constexpr (N > 1) l1.finish(st, lds, R, a);
         if constexpr (N > 2) l2.finish(st, lds, R, a);
@@ -430,12 +463,40 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
                                              uint32_t& esign_hi) {
     constexpr int NG = LayerGroups<BG, NL>::ngroups();
     __syncthreads(); // ends group GI-1 (for GI == 0: the previous iteration / the prologue)
+#if NRLDPC_Z64_POSTBAR
+    // Variant: the group's own early part (its LDS reads were issued before the barrier) is tracked AFTER the barrier, in
+    // the shadow of the late reads' LDS round trip, instead of before it; only the next group's early READS precede the
+    // next barrier.  Every wave of a SIMD leaves a barrier at the same time, so with the early part already done nothing
+    // is left to issue while the late reads are in flight.
+    cur.template loads<true>(lds, R);
+    cur.template track<false, XF>(st, cap);
+    cur.template track<true, XF>(st, cap);
+    if constexpr (GI + 1 < NG) {
+        GroupZ64<BG, ZC, GI + 1, NL> nxt;
+        nxt.template loads<false>(lds, R);
+        cur.finish(st, lds, R, a);
+        cur.twins(lds, RA, RB, w);
+        if constexpr (ET) {
+            cur.ext(a, esign_lo, esign_hi);
+            asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
+        }
+        pipeline_z64<BG, ZC, GI + 1, ET, NL, XF>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+    } else {
+        next0.template loads<false>(lds, R);
+        cur.finish(st, lds, R, a);
+        cur.twins(lds, RA, RB, w);
+        if constexpr (ET) {
+            cur.ext(a, esign_lo, esign_hi);
+            asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
+        }
+    }
+#else
     __builtin_amdgcn_s_setprio(NRLDPC_Z64_PRIO); // urgent until this group's writes are out (see NRLDPC_Z64_PRIO)
     cur.template loads<true>(lds, R);
     if constexpr (GI + 1 < NG) {
         GroupZ64<BG, ZC, GI + 1, NL> nxt;
         nxt.template loads<false>(lds, R); // columns untouched by group GI: safe before its writes
-        cur.template track<true>(st, cap);
+        cur.template track<true, XF>(st, cap);
         cur.finish(st, lds, R, a);
         cur.twins(lds, RA, RB, w);
         __builtin_amdgcn_s_setprio(0); // the next group's early part only fills gaps
@@ -449,7 +510,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
         pipeline_z64<BG, ZC, GI + 1, ET, NL, XF>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
     } else {
         next0.template loads<false>(lds, R);
-        cur.template track<true>(st, cap);
+        cur.template track<true, XF>(st, cap);
         cur.finish(st, lds, R, a);
         cur.twins(lds, RA, RB, w);
         __builtin_amdgcn_s_setprio(0); // the next group's early part only fills gaps
@@ -459,6 +520,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
         }
         next0.template track<false, XF>(st, cap);
     }
+#endif
 }
 
 template <int BG, int ZC, int L>
@@ -661,7 +723,9 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             }
             GroupZ64<BG, ZC, 0, NL> g0;
             g0.template loads<false>(lds, R);
+#if !NRLDPC_Z64_POSTBAR
             g0.template track<false, XF>(st, cap);
+#endif
             for (int it = 1; it <= a.max_iter; ++it) {
                 GroupZ64<BG, ZC, 0, NL> nx;
                 pipeline_z64<BG, ZC, 0, false, NL, XF>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
@@ -716,7 +780,9 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         if (active) {
             GroupZ64<BG, ZC, 0, NL> g0;
             g0.template loads<false>(lds, R);
+#if !NRLDPC_Z64_POSTBAR
             g0.template track<false>(st, cap);
+#endif
             for (; it <= a.max_iter; ++it) {
                 esign_lo = 0; esign_hi = 0;
                 GroupZ64<BG, ZC, 0, NL> nx;
@@ -818,7 +884,21 @@ template <int BG, int ZC, int NCWG, int NL> static hipError_t launch_z64_pruned(
     return launch_z64f<BG, ZC, NCWG, true, true, false, NL>(a, s);
 }
 
+} // namespace nrldpc
+#include "nrldpc_decode_z64s.h" // the two-threads-per-row form of the same decoder
+namespace nrldpc {
+
+#ifndef NRLDPC_Z64_SPLIT
+#define NRLDPC_Z64_SPLIT 0
+#endif
+
 template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
+#if NRLDPC_Z64_SPLIT
+    if constexpr (Z64S<BG, ZC, BGT<BG>::ROWS>::usable()) {
+        if (a.n_layers == BGD<BG>::ROWS && !a.app)
+            return a.early_term ? launch_z64s<BG, ZC, true>(a, s) : launch_z64s<BG, ZC, false>(a, s);
+    }
+#endif
     static const bool no_pruned = getenv("NRLDPC_NO_PRUNED_PIPELINE") != nullptr; // A/B against the general kernel
     if (!a.app && !no_pruned) {
         // layer counts of the rate-matching points BASELINE.json names have pipelined builds of their own

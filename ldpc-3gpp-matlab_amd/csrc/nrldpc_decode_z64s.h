@@ -1,0 +1,311 @@
+// nrldpc_decode_z64s.h -- "split" form of the compile-time-Z decoder (nrldpc_decode_z64.h): TWO threads per check row.
+//
+// The one-thread-per-row kernel keeps all of a row's check-to-variable messages in its thread's registers (BG1: 69 + 11
+// VGPRs of state), which leaves room for 3 waves per SIMD at Z = 384, all of one workgroup and in step with each other:
+// its VALU pipes are busy ~70 % of the time.  Here the column-disjoint barrier groups of the
+// layered schedule ALTERNATE between two threads of the same row ("halves" H = 0 / 1 of the workgroup):
+//
+//   interval gi (between two workgroup barriers):   half gi % 2       finishes group gi   (late reads, pass 2, LDS writes)
+//                                                   half (gi+1) % 2   prepares group gi+1 (early reads + min search)
+//
+// -- exactly the two parts the software pipeline of pipeline_z64 runs back to back in ONE wave, now in different waves.
+// Each thread holds the messages of every other group only (half the state registers), so twice the waves fit:
+// one codeword = 2 * Z/64 waves = one workgroup, two workgroups per CU, 6 waves per SIMD.  The instruction count per
+// codeword is unchanged (every edge is still processed once, by one thread); what changes is that the preparing half's
+// work is always there to fill the finishing half's LDS round trips, and that the two codewords of a CU no longer share
+// a barrier.  Results are identical (same arithmetic in the same order per row; min / med3 / xor are order-independent).
+//
+// Requires an even number of barrier groups (so that the alternation is the same in every iteration): BG1 all rows 32,
+// BG2 all rows 28.
+#ifndef NRLDPC_DECODE_Z64S_H
+#define NRLDPC_DECODE_Z64S_H
+#include "nrldpc_decode_z64.h"
+
+namespace nrldpc {
+
+#ifndef NRLDPC_Z64S_WPE
+#define NRLDPC_Z64S_WPE 6 // waves per SIMD the register allocation is sized for (two 12-wave workgroups per CU at Z = 384)
+#endif
+#ifndef NRLDPC_Z64S_XF
+#define NRLDPC_Z64S_XF 0 // extension LLRs as floats (1) or packed int8 (0)
+#endif
+
+template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
+    using B = Z64<BG, ZC, 1, NL>;
+    static constexpr int NG = LayerGroups<BG, NL>::ngroups();
+    static constexpr int THREADS = 2 * B::TPC;
+    static constexpr bool usable() { return NG % 2 == 0 && B::BLK == 64 && THREADS <= 1024; }
+    static constexpr size_t lds_bytes() { return (size_t)B::CWS + B::GUARD + 16; }
+};
+
+template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
+__device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)],
+                                        uint32_t RA, uint32_t RB, int w, const DecArgs& a, float cap, uint32_t& esign_lo,
+                                        uint32_t& esign_hi);
+
+// interval GI, this half owns group GI: `cur` arrives with its early part done
+template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
+__device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds,
+                                       const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
+                                       float cap, uint32_t& esign_lo, uint32_t& esign_hi) {
+    constexpr int NG = LayerGroups<BG, NL>::ngroups();
+    __syncthreads(); // ends interval GI-1: group GI-1's writes are visible
+    __builtin_amdgcn_s_setprio(2); // the next barrier waits for this half
+    cur.template loads<true>(lds, R);
+    cur.template track<true, XF>(st, cap);
+    cur.finish(st, lds, R, a);
+    cur.twins(lds, RA, RB, w);
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (ET) {
+        cur.ext(a, esign_lo, esign_hi);
+        asm volatile("" : "+v"(esign_lo), "+v"(esign_hi)); // see pipeline_z64
+    }
+    if constexpr (GI + 1 < NG)
+        s_early<BG, ZC, NL, H, ET, XF, GI + 1>(next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+}
+
+// interval GI, the other half owns group GI: this half prepares group GI+1 (cyclically: group 0 of the next iteration)
+template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
+__device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)],
+                                        uint32_t RA, uint32_t RB, int w, const DecArgs& a, float cap, uint32_t& esign_lo,
+                                        uint32_t& esign_hi) {
+    constexpr int NG = LayerGroups<BG, NL>::ngroups();
+    __syncthreads();
+    if constexpr (GI + 1 < NG) {
+        GroupZ64<BG, ZC, GI + 1, NL, H> nxt;
+        nxt.template loads<false>(lds, R); // columns group GI does not write
+        nxt.template track<false, XF>(st, cap);
+        s_crit<BG, ZC, NL, H, ET, XF, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+    } else {
+        next0.template loads<false>(lds, R);
+        next0.template track<false, XF>(st, cap);
+    }
+}
+
+template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS>
+__global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_decode_z64s_kernel(const DecArgs a) {
+    using G = Z64S<BG, ZC, NL>;
+    using LGN = LayerGroups<BG, NL>;
+    static_assert(G::usable(), "split kernel: even group count, 64-row waves, at most 1024 threads");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave / G::NWV, w = wave % G::NWV, lane = tid & 63;
+    const int z = w * 64 + lane;
+    const int cw = blockIdx.x;
+    int* flags = reinterpret_cast<int*>(lds + (size_t)G::CWS + G::GUARD);
+    constexpr size_t ncwz = (size_t)G::COLS * ZC;
+    constexpr bool XF = NRLDPC_Z64S_XF != 0;
+
+    uint32_t R[G::NWV];
+#pragma unroll
+    for (int k = 0; k < G::NWV; ++k) R[k] = G::GUARD + 256u * (uint32_t)((w + k) % G::NWV) + 4u * (uint32_t)lane;
+    const uint32_t RA = (uint32_t)(G::GUARD - 256) + 4u * (uint32_t)lane;
+    const uint32_t RB = G::GUARD + 4u * ZC + 4u * (uint32_t)lane;
+    const size_t base = (size_t)cw * ncwz;
+
+    // ---- core columns -> LDS: ZC/4 threads cover a column with 4 consecutive ring positions each, 8 columns per pass
+    {
+        constexpr int QW = ZC / 4;
+        const int qs = tid / QW, qq = tid - qs * QW;
+        constexpr int NP = (G::NC + 7) / 8;
+        const bool wide = (reinterpret_cast<uintptr_t>(a.llr) & 15) == 0;
+        auto ingest_as = [&](auto kind_c) {
+            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
+            if (wide) {
+                uint4 x[NP];
+                static_for<NP>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const int c = 8 * k + qs;
+                    x[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (8 * k + 7 < G::NC || c < G::NC) {
+                        const size_t i = base + (size_t)c * ZC + 4 * qq;
+                        if constexpr (F16) {
+                            const uint2 r = *reinterpret_cast<const uint2*>(static_cast<const __half*>(a.llr) + i);
+                            x[k].x = r.x; x[k].y = r.y;
+                        } else {
+                            x[k] = *reinterpret_cast<const uint4*>(static_cast<const float*>(a.llr) + i);
+                        }
+                    }
+                });
+                static_for<NP>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const int c = 8 * k + qs;
+                    if (8 * k + 7 < G::NC || c < G::NC) {
+                        float4 v;
+                        if constexpr (F16) {
+                            const __half2 lo = *reinterpret_cast<const __half2*>(&x[k].x), hi = *reinterpret_cast<const __half2*>(&x[k].y);
+                            v = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
+                        } else {
+                            v = make_float4(__uint_as_float(x[k].x), __uint_as_float(x[k].y), __uint_as_float(x[k].z), __uint_as_float(x[k].w));
+                        }
+                        const float4 q = make_float4(ingest(v.x, a.scale, true), ingest(v.y, a.scale, true),
+                                                     ingest(v.z, a.scale, true), ingest(v.w, a.scale, true));
+                        char* col = lds + G::GUARD + c * G::CS;
+                        *reinterpret_cast<float4*>(col + 16 * qq) = q;
+                        if (qq < 16) *reinterpret_cast<float4*>(col + 4 * ZC + 16 * qq) = q; // mirror of block 0
+                    }
+                });
+            } else { // unaligned LLR pointer: one ring position per thread, the halves take alternate columns
+                constexpr int NPU = (G::NC + 1) / 2;
+                uint32_t x[NPU];
+                static_for<NPU>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const int c = 2 * k + half;
+                    x[k] = 0u;
+                    if (2 * k + 1 < G::NC || c < G::NC) {
+                        if constexpr (F16) x[k] = static_cast<const uint16_t*>(a.llr)[base + (size_t)c * ZC + z];
+                        else x[k] = static_cast<const uint32_t*>(a.llr)[base + (size_t)c * ZC + z];
+                    }
+                });
+                static_for<NPU>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const int c = 2 * k + half;
+                    if (2 * k + 1 < G::NC || c < G::NC) {
+                        float v;
+                        if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)x[k]));
+                        else v = __uint_as_float(x[k]);
+                        const float q = ingest(v, a.scale, true);
+                        char* home = lds + G::GUARD + 4 * z + c * G::CS;
+                        *reinterpret_cast<float*>(home) = q;
+                        if (w == 0) *reinterpret_cast<float*>(home + ZC * 4) = q;
+                    }
+                });
+            }
+        };
+        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
+    }
+
+    int my_iters = a.max_iter;
+    // One half's whole decode.  Instantiated twice; the branch on `half` is wave-uniform.
+    auto run = [&](auto hc, auto kind_c) {
+        constexpr int H = decltype(hc)::value;
+        constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16; // a body per LLR format: no format test per load
+        using O = Own<BG, NL, H>;
+        DecStateS<BG, NL, H> st;
+#pragma unroll
+        for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
+#pragma unroll
+        for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
+        // extension LLRs of this half's rows: thread-private, one load per row; raw bits first, conversions after
+        {
+            uint32_t xe[O::NEXT > 0 ? O::NEXT : 1];
+            static_for<NL - 4>([&](auto ic) {
+                constexpr int L = 4 + decltype(ic)::value;
+                if constexpr (O::mine(L)) {
+                    constexpr int xi = O::ext_index(L);
+                    const size_t i = base + (size_t)(G::NC + L - 4) * ZC + z;
+                    if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
+                    else xe[xi] = static_cast<const uint32_t*>(a.llr)[i];
+                }
+            });
+            static_for<O::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float v;
+                if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)xe[i]));
+                else v = __uint_as_float(xe[i]);
+                f32_to_byte<i & 3>(st.xq[i >> 2], ingest(v, a.scale, false));
+            });
+            if constexpr (XF) {
+                static_for<O::NEXT>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    st.xf[i] = byte_to_f32<i & 3>(st.xq[i >> 2]);
+                });
+            }
+        }
+        __syncthreads(); // the a-posteriori rings are complete
+        const float cap = (127.49f + a.beta) / a.alpha; // see LayerZ64::track3
+        DecArgs av = a;                                  // alpha, 2^23 - beta as VGPR values: see the one-thread-per-row kernel
+        av.beta = 8388608.0f - a.beta;
+        asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
+        uint32_t esign_lo = 0, esign_hi = 0;
+        GroupZ64<BG, ZC, 0, NL, H> g0;
+        if constexpr (H == 0) {
+            g0.template loads<false>(lds, R);
+            g0.template track<false, XF>(st, cap);
+        }
+        for (int it = 1; it <= a.max_iter; ++it) {
+            if constexpr (ETP) { esign_lo = 0; esign_hi = 0; }
+            if constexpr (H == 0) {
+                GroupZ64<BG, ZC, 0, NL, H> nx;
+                s_crit<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
+                g0 = nx;
+            } else {
+                s_early<BG, ZC, NL, H, ETP, XF, 0>(g0, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
+            }
+            if constexpr (ETP) {
+                // parity check of this half's rows (see parity_pass of the one-thread-per-row kernel)
+                if (tid == 0) flags[0] = 0;
+                __syncthreads();
+                uint32_t bad = 0;
+                bool stop = false; // wave-uniform
+                static_for<NL>([&](auto lc) {
+                    constexpr int L = decltype(lc)::value;
+                    if constexpr (O::mine(L)) {
+                        if (!stop) {
+                            bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                            if constexpr (L < 4 || (O::ext_index(L) % 4) == 3) stop = __any((int)bad) != 0;
+                        }
+                    }
+                });
+                if (bad) flags[0] = 1;
+                __syncthreads();
+                if (__builtin_amdgcn_readfirstlane(flags[0]) == 0) { my_iters = it; break; }
+            }
+        }
+        if constexpr (!ETP) __syncthreads(); // the last group's writes
+    };
+    using KF16 = std::integral_constant<int, NRLDPC_K_F16>;
+    using KF32 = std::integral_constant<int, NRLDPC_K_F32>;
+    if (half == 0) {
+        if (a.llr_kind == NRLDPC_K_F16) run(std::integral_constant<int, 0>{}, KF16{});
+        else run(std::integral_constant<int, 0>{}, KF32{});
+    } else {
+        if (a.llr_kind == NRLDPC_K_F16) run(std::integral_constant<int, 1>{}, KF16{});
+        else run(std::integral_constant<int, 1>{}, KF32{});
+    }
+
+    if (a.iters && tid == 0) a.iters[cw] = my_iters;
+    uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * ZC);
+    if ((reinterpret_cast<uintptr_t>(a.hard) & 3) == 0) {
+        constexpr int QW = ZC / 4;
+        const int qs = tid / QW, qq = tid - qs * QW;
+        static_for<(G::KB + 7) / 8>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const int c = 8 * k + qs;
+            if (8 * k + 7 < G::KB || c < G::KB) {
+                const float4 v = *reinterpret_cast<const float4*>(lds + G::GUARD + c * G::CS + 16 * qq);
+                const uint32_t bits = (v.x < 0.0f ? 1u : 0u) | (v.y < 0.0f ? 0x100u : 0u) | (v.z < 0.0f ? 0x10000u : 0u) |
+                                      (v.w < 0.0f ? 0x1000000u : 0u);
+                *reinterpret_cast<uint32_t*>(hard + (size_t)c * ZC + 4 * qq) = bits;
+            }
+        });
+    } else {
+        static_for<(G::KB + 1) / 2>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const int c = 2 * k + half;
+            if (2 * k + 1 < G::KB || c < G::KB)
+                hard[(size_t)c * ZC + z] = *reinterpret_cast<const float*>(lds + G::GUARD + 4 * z + c * G::CS) < 0.0f ? 1 : 0;
+        });
+    }
+}
+
+template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t launch_z64s(const DecArgs& a, hipStream_t s) {
+    using G = Z64S<BG, ZC, NL>;
+    auto k = nrldpc_decode_z64s_kernel<BG, ZC, ETP, NL>;
+    constexpr size_t lds = G::lds_bytes();
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(a.batch), dim3(G::THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+} // namespace nrldpc
+#endif

@@ -85,6 +85,33 @@ template <int BG, int NL = BGT<BG>::ROWS> struct LayerGroups {
     static constexpr unsigned long long group_mask(int gi) { return T.gmask[gi]; }
 };
 
+// Ownership of layers by threads.  H < 0: a thread owns its check row in every layer (one thread per row of a codeword).
+// H = 0 / 1 ("split" kernels, nrldpc_decode_z64s.h): a row has TWO threads; the barrier groups alternate between them, so
+// each holds the messages (and extension LLRs) of every other group only -- about half the registers, twice the waves.
+template <int BG, int NL, int H> struct Own {
+    using G = BGD<BG>;
+    using LG = LayerGroups<BG, NL>;
+    static constexpr bool mine(int L) { return H < 0 || LG::group_index(L) % 2 == H; }
+    static constexpr int ncore(int L) { return G::row_ptr(L + 1) - G::row_ptr(L) - (L >= 4 ? 1 : 0); }
+    // index of the first message byte of layer L in this thread's compact message store
+    static constexpr int core_base(int L) {
+        if (H < 0) return G::core_base(L);
+        int n = 0;
+        for (int l = 0; l < L; ++l) n += mine(l) ? ncore(l) : 0;
+        return n;
+    }
+    // index of layer L's extension LLR (L >= 4) in this thread's store
+    static constexpr int ext_index(int L) {
+        if (H < 0) return L - 4;
+        int n = 0;
+        for (int l = 4; l < L; ++l) n += mine(l) ? 1 : 0;
+        return n;
+    }
+    static constexpr int NCORE = H < 0 ? G::NCORE : core_base(NL);
+    static constexpr int NEXT = H < 0 ? G::NEXT : ext_index(NL);
+    static constexpr int NW = (NCORE + 3) / 4, NXW = (NEXT + 3) / 4;
+};
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -169,6 +196,13 @@ template <int BG> struct DecState {
     // the same LLRs as floats, for the builds whose register budget has room for them (one v_cvt_f32_i32_sdwa per
     // extension row and iteration saved); never touched -- so never allocated -- by the others
     float xf[BGD<BG>::NEXT];
+};
+
+// per-thread state of a split kernel's half H (see Own)
+template <int BG, int NL, int H> struct DecStateS {
+    uint32_t rm[Own<BG, NL, H>::NW];
+    uint32_t xq[Own<BG, NL, H>::NXW];
+    float xf[Own<BG, NL, H>::NEXT > 0 ? Own<BG, NL, H>::NEXT : 1];
 };
 
 // The same for the software-pipelined builds, with nbeta23 = 2^23 - beta held in a VGPR: v_fma + v_max + v_sub

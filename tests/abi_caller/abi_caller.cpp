@@ -35,6 +35,7 @@ int main(int argc, char** argv) {
     // error convention first: an invalid lifting size is "unsupported", not a crash (get_3gpp_set_index.m:10)
     nrldpc_cfg bad;
     std::memset(&bad, 0, sizeof bad);
+    bad.struct_size = sizeof bad;
     bad.bg = bg; bad.Z = 100; bad.max_iter = iters; bad.llr_dtype = NRLDPC_LLR_F64;
     nrldpc_handle h = nullptr;
     CHECK(nrldpc_create(&bad, &h) == NRLDPC_ERR_UNSUPPORTED && h == nullptr, "invalid Z is NRLDPC_ERR_UNSUPPORTED");
@@ -43,9 +44,13 @@ int main(int argc, char** argv) {
     nrldpc_cfg cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.bg = bg; cfg.Z = Z; cfg.max_iter = iters; cfg.early_term = 1;   // NRLDPCDecoder.m:120
+    CHECK(nrldpc_create(&cfg, &h) == NRLDPC_ERR_ARG && h == nullptr, "a cfg without struct_size (other ABI revision) is refused");
+    cfg.struct_size = sizeof cfg;
     cfg.llr_dtype = NRLDPC_LLR_F64;                                     // MATLAB doubles; alpha = 0: the library's rule
     CHECK(nrldpc_create(&cfg, &h) == NRLDPC_OK, "nrldpc_create");
     nrldpc_dims d;
+    d.struct_size = sizeof d;
+    CHECK(nrldpc_abi_version() == NRLDPC_ABI_VERSION, "header and library are the same ABI revision");
     CHECK(nrldpc_get_dims(h, &d) == NRLDPC_OK, "nrldpc_get_dims");
     float ra = 0, rb = 0;
     CHECK(nrldpc_default_rule(bg, 0, &ra, &rb) == NRLDPC_OK && ra == d.alpha && rb == d.beta, "create applied nrldpc_default_rule");
