@@ -877,28 +877,43 @@ static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the pipelined pair (fixed iteration count / early termination) for a compile-time pruned layer count: its own
-// translation unit (nrldpc_decode_z64_inst.hip with -DNRLDPC_Z64_NL=<count>)
-template <int BG, int ZC, int NCWG, int NL> static hipError_t launch_z64_pruned(const DecArgs& a, hipStream_t s) {
-    if (a.early_term) return launch_z64f<BG, ZC, NCWG, true, false, true, NL>(a, s);
-    return launch_z64f<BG, ZC, NCWG, true, true, false, NL>(a, s);
-}
-
 } // namespace nrldpc
 #include "nrldpc_decode_z64s.h" // the two-threads-per-row form of the same decoder
 namespace nrldpc {
 
-#ifndef NRLDPC_Z64_SPLIT
-#define NRLDPC_Z64_SPLIT 0
+// Which form serves a (BG, Z, layer count): NRLDPC_SPLIT=0 / 1 in the environment forces one (A/B on the MI355X:
+// tools/bench_all_z.py); otherwise z64_split_default, the measured choice.
+inline int split_env() {
+    static const int v = getenv("NRLDPC_SPLIT") ? atoi(getenv("NRLDPC_SPLIT")) : -1;
+    return v;
+}
+template <int BG, int ZC, int NL> constexpr bool z64_split_default() {
+#ifdef NRLDPC_Z64_SPLIT
+    return NRLDPC_Z64_SPLIT != 0;
 #endif
+    return BG == 1 && ZC == 384 && NL == BGT<BG>::ROWS;
+}
+template <int BG, int ZC, int NL> static bool use_split() {
+    if constexpr (!Z64S<BG, ZC, NL>::usable()) return false;
+    const int e = split_env();
+    return e < 0 ? z64_split_default<BG, ZC, NL>() : e != 0;
+}
+
+// the pipelined pair (fixed iteration count / early termination) for a compile-time pruned layer count: its own
+// translation unit (nrldpc_decode_z64_inst.hip with -DNRLDPC_Z64_NL=<count>)
+template <int BG, int ZC, int NCWG, int NL> static hipError_t launch_z64_pruned(const DecArgs& a, hipStream_t s) {
+    if constexpr (Z64S<BG, ZC, NL>::usable()) {
+        if (use_split<BG, ZC, NL>()) return a.early_term ? launch_z64s<BG, ZC, true, NL>(a, s) : launch_z64s<BG, ZC, false, NL>(a, s);
+    }
+    if (a.early_term) return launch_z64f<BG, ZC, NCWG, true, false, true, NL>(a, s);
+    return launch_z64f<BG, ZC, NCWG, true, true, false, NL>(a, s);
+}
 
 template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
-#if NRLDPC_Z64_SPLIT
     if constexpr (Z64S<BG, ZC, BGT<BG>::ROWS>::usable()) {
-        if (a.n_layers == BGD<BG>::ROWS && !a.app)
+        if (a.n_layers == BGD<BG>::ROWS && !a.app && use_split<BG, ZC, BGT<BG>::ROWS>())
             return a.early_term ? launch_z64s<BG, ZC, true>(a, s) : launch_z64s<BG, ZC, false>(a, s);
     }
-#endif
     static const bool no_pruned = getenv("NRLDPC_NO_PRUNED_PIPELINE") != nullptr; // A/B against the general kernel
     if (!a.app && !no_pruned) {
         // layer counts of the rate-matching points BASELINE.json names have pipelined builds of their own

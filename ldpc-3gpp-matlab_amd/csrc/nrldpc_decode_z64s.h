@@ -26,6 +26,12 @@ namespace nrldpc {
 #ifndef NRLDPC_Z64S_WPE
 #define NRLDPC_Z64S_WPE 6 // waves per SIMD the register allocation is sized for (two 12-wave workgroups per CU at Z = 384)
 #endif
+#ifndef NRLDPC_Z64S_RULE_SGPR
+#define NRLDPC_Z64S_RULE_SGPR 1 // alpha, 2^23 - beta as scalar operands (two 4-cycle ops per row instead of 2 VGPRs)
+#endif
+#ifndef NRLDPC_Z64S_PRIO
+#define NRLDPC_Z64S_PRIO 2
+#endif
 #ifndef NRLDPC_Z64S_XF
 #define NRLDPC_Z64S_XF 0 // extension LLRs as floats (1) or packed int8 (0)
 #endif
@@ -34,7 +40,7 @@ template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
     using B = Z64<BG, ZC, 1, NL>;
     static constexpr int NG = LayerGroups<BG, NL>::ngroups();
     static constexpr int THREADS = 2 * B::TPC;
-    static constexpr bool usable() { return NG % 2 == 0 && B::BLK == 64 && THREADS <= 1024; }
+    static constexpr bool usable() { return THREADS <= 1024 && NG >= 2; }
     static constexpr size_t lds_bytes() { return (size_t)B::CWS + B::GUARD + 16; }
 };
 
@@ -50,7 +56,7 @@ __device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ6
                                        float cap, uint32_t& esign_lo, uint32_t& esign_hi) {
     constexpr int NG = LayerGroups<BG, NL>::ngroups();
     __syncthreads(); // ends interval GI-1: group GI-1's writes are visible
-    __builtin_amdgcn_s_setprio(2); // the next barrier waits for this half
+    __builtin_amdgcn_s_setprio(NRLDPC_Z64S_PRIO); // the next barrier waits for this half
     cur.template loads<true>(lds, R);
     cur.template track<true, XF>(st, cap);
     cur.finish(st, lds, R, a);
@@ -60,8 +66,14 @@ __device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ6
         cur.ext(a, esign_lo, esign_hi);
         asm volatile("" : "+v"(esign_lo), "+v"(esign_hi)); // see pipeline_z64
     }
-    if constexpr (GI + 1 < NG)
+    if constexpr (GI + 1 < NG) {
         s_early<BG, ZC, NL, H, ET, XF, GI + 1>(next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+    } else if constexpr (H == 0) {
+        // odd group count: this half owns the last group AND group 0, whose early part it runs right here (the one
+        // interval per iteration that is software-pipelined within a wave, as in pipeline_z64)
+        next0.template loads<false>(lds, R);
+        next0.template track<false, XF>(st, cap);
+    }
 }
 
 // interval GI, the other half owns group GI: this half prepares group GI+1 (cyclically: group 0 of the next iteration)
@@ -76,7 +88,7 @@ __device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& s
         nxt.template loads<false>(lds, R); // columns group GI does not write
         nxt.template track<false, XF>(st, cap);
         s_crit<BG, ZC, NL, H, ET, XF, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
-    } else {
+    } else if constexpr (H == 0) { // even group count: the last group is the other half's, group 0 is this one's
         next0.template loads<false>(lds, R);
         next0.template track<false, XF>(st, cap);
     }
@@ -86,12 +98,16 @@ template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS>
 __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_decode_z64s_kernel(const DecArgs a) {
     using G = Z64S<BG, ZC, NL>;
     using LGN = LayerGroups<BG, NL>;
-    static_assert(G::usable(), "split kernel: even group count, 64-row waves, at most 1024 threads");
+    static_assert(G::usable(), "split kernel: at most 1024 threads");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave / G::NWV, w = wave % G::NWV, lane = tid & 63;
-    const int z = w * 64 + lane;
+    if constexpr (G::BLK < 64) {
+        if (lane >= G::BLK) return; // these lanes own no row; barriers count waves, not lanes
+    }
+    const int z = w * G::BLK + lane;
+    const int u = half * ZC + z; // dense index of this thread among the 2 Z threads that own rows
     const int cw = blockIdx.x;
     int* flags = reinterpret_cast<int*>(lds + (size_t)G::CWS + G::GUARD);
     constexpr size_t ncwz = (size_t)G::COLS * ZC;
@@ -99,15 +115,15 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
 
     uint32_t R[G::NWV];
 #pragma unroll
-    for (int k = 0; k < G::NWV; ++k) R[k] = G::GUARD + 256u * (uint32_t)((w + k) % G::NWV) + 4u * (uint32_t)lane;
-    const uint32_t RA = (uint32_t)(G::GUARD - 256) + 4u * (uint32_t)lane;
+    for (int k = 0; k < G::NWV; ++k) R[k] = G::GUARD + (uint32_t)(4 * G::BLK) * (uint32_t)((w + k) % G::NWV) + 4u * (uint32_t)lane;
+    const uint32_t RA = (uint32_t)(G::GUARD - 4 * G::BLK) + 4u * (uint32_t)lane;
     const uint32_t RB = G::GUARD + 4u * ZC + 4u * (uint32_t)lane;
     const size_t base = (size_t)cw * ncwz;
 
     // ---- core columns -> LDS: ZC/4 threads cover a column with 4 consecutive ring positions each, 8 columns per pass
     {
         constexpr int QW = ZC / 4;
-        const int qs = tid / QW, qq = tid - qs * QW;
+        const int qs = u / QW, qq = u - qs * QW;
         constexpr int NP = (G::NC + 7) / 8;
         const bool wide = (reinterpret_cast<uintptr_t>(a.llr) & 15) == 0;
         auto ingest_as = [&](auto kind_c) {
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                                                      ingest(v.z, a.scale, true), ingest(v.w, a.scale, true));
                         char* col = lds + G::GUARD + c * G::CS;
                         *reinterpret_cast<float4*>(col + 16 * qq) = q;
-                        if (qq < 16) *reinterpret_cast<float4*>(col + 4 * ZC + 16 * qq) = q; // mirror of block 0
+                        if (qq < G::BLK / 4) *reinterpret_cast<float4*>(col + 4 * ZC + 16 * qq) = q; // mirror of block 0
                     }
                 });
             } else { // unaligned LLR pointer: one ring position per thread, the halves take alternate columns
@@ -179,17 +195,18 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
 
     int my_iters = a.max_iter;
     // One half's whole decode.  Instantiated twice; the branch on `half` is wave-uniform.
-    auto run = [&](auto hc, auto kind_c) {
+    auto run = [&](auto hc) {
         constexpr int H = decltype(hc)::value;
-        constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16; // a body per LLR format: no format test per load
         using O = Own<BG, NL, H>;
         DecStateS<BG, NL, H> st;
 #pragma unroll
         for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
 #pragma unroll
         for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
-        // extension LLRs of this half's rows: thread-private, one load per row; raw bits first, conversions after
-        {
+        // extension LLRs of this half's rows: thread-private, one load per row; raw bits first, conversions after, in a
+        // body per LLR format (no format test per load: see the prologue of the one-thread-per-row kernel)
+        auto load_ext = [&](auto kind_c) {
+            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
             uint32_t xe[O::NEXT > 0 ? O::NEXT : 1];
             static_for<NL - 4>([&](auto ic) {
                 constexpr int L = 4 + decltype(ic)::value;
@@ -207,18 +224,22 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                 else v = __uint_as_float(xe[i]);
                 f32_to_byte<i & 3>(st.xq[i >> 2], ingest(v, a.scale, false));
             });
-            if constexpr (XF) {
-                static_for<O::NEXT>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    st.xf[i] = byte_to_f32<i & 3>(st.xq[i >> 2]);
-                });
-            }
+        };
+        if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});
+        else load_ext(std::integral_constant<int, NRLDPC_K_F32>{});
+        if constexpr (XF) {
+            static_for<O::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                st.xf[i] = byte_to_f32<i & 3>(st.xq[i >> 2]);
+            });
         }
         __syncthreads(); // the a-posteriori rings are complete
         const float cap = (127.49f + a.beta) / a.alpha; // see LayerZ64::track3
         DecArgs av = a;                                  // alpha, 2^23 - beta as VGPR values: see the one-thread-per-row kernel
         av.beta = 8388608.0f - a.beta;
+#if !NRLDPC_Z64S_RULE_SGPR
         asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
+#endif
         uint32_t esign_lo = 0, esign_hi = 0;
         GroupZ64<BG, ZC, 0, NL, H> g0;
         if constexpr (H == 0) {
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
             }
             if constexpr (ETP) {
                 // parity check of this half's rows (see parity_pass of the one-thread-per-row kernel)
-                if (tid == 0) flags[0] = 0;
+                if (u == 0) flags[0] = 0;
                 __syncthreads();
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform
@@ -256,21 +277,14 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
         }
         if constexpr (!ETP) __syncthreads(); // the last group's writes
     };
-    using KF16 = std::integral_constant<int, NRLDPC_K_F16>;
-    using KF32 = std::integral_constant<int, NRLDPC_K_F32>;
-    if (half == 0) {
-        if (a.llr_kind == NRLDPC_K_F16) run(std::integral_constant<int, 0>{}, KF16{});
-        else run(std::integral_constant<int, 0>{}, KF32{});
-    } else {
-        if (a.llr_kind == NRLDPC_K_F16) run(std::integral_constant<int, 1>{}, KF16{});
-        else run(std::integral_constant<int, 1>{}, KF32{});
-    }
+    if (half == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
 
-    if (a.iters && tid == 0) a.iters[cw] = my_iters;
+    if (a.iters && u == 0) a.iters[cw] = my_iters;
     uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * ZC);
     if ((reinterpret_cast<uintptr_t>(a.hard) & 3) == 0) {
         constexpr int QW = ZC / 4;
-        const int qs = tid / QW, qq = tid - qs * QW;
+        const int qs = u / QW, qq = u - qs * QW;
         static_for<(G::KB + 7) / 8>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const int c = 8 * k + qs;

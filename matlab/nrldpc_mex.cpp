@@ -17,10 +17,16 @@
 //   cw           = nrldpc_mex('encode', id, c)          c: K x C double in {0,1} (no NaN) -> (N+2*Z_c) x C double
 //   [a, b]       = nrldpc_mex('default_rule', BG, n_layers)
 //   nrldpc_mex('destroy', id)
+//   One MATLAB process, several GPUs (nrldpc_pool_*: codeword batches shard with no collective; plot_BLER_vs_SNR.m:23-27
+//   runs "parallel instances" by hand instead):
+//   pid          = nrldpc_mex('pool_create', BG, Z_c, iterations, device_ids [, chunks_per_device [, n_layers]])
+//   [c_hat, it]  = nrldpc_mex('pool_decode', pid, cw_tilde)   any number of columns, dealt to the GPUs of the pool
+//   nrldpc_mex('pool_destroy', pid)
 // Errors carry the reference's two identifiers (NRLDPCDecoder.m:149, NRLDPC.m:240-294): callers that catch
 // 'ldpc_3gpp_matlab:UnsupportedParameters' and skip (plot_BLER_vs_SNR.m:173, testbench.m:51) keep working.
 //
-// This file cannot be compiled in the build image or on the GPU box (no MATLAB, no mex.h); the same entry points are
+// This file cannot be built into a MEX file in the build image or on the GPU box (no MATLAB); the CPU suite compile-checks
+// it against a stub of the MEX API (tests/mex_stub/mex.h, tests/test_capi_symbols.py), and the same entry points are
 // driven the same way -- host pointers, doubles in, one call per batch of columns -- by tests/abi_caller/abi_caller.cpp.
 #include <cstdint>
 #include <cstring>
@@ -33,12 +39,18 @@
 namespace {
 
 std::map<uint64_t, nrldpc_handle> g_handles; // registry of live codecs; the MEX file stays locked while it is non-empty
+struct Pool { nrldpc_pool_handle p; nrldpc_dims d; };
+std::map<uint64_t, Pool> g_pools;             // ... or this one
 uint64_t g_next = 1;
 
 void at_exit() {
     for (auto& kv : g_handles) nrldpc_destroy(kv.second);
     g_handles.clear();
+    for (auto& kv : g_pools) nrldpc_pool_destroy(kv.second.p);
+    g_pools.clear();
 }
+
+bool registry_empty() { return g_handles.empty() && g_pools.empty(); }
 
 void check(int rc) {
     if (rc == NRLDPC_OK) return;
@@ -68,6 +80,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         need(nrhs >= 4, "create needs BG, Z_c and iterations.");
         nrldpc_cfg cfg;
         memset(&cfg, 0, sizeof cfg);
+        cfg.struct_size = sizeof cfg;
         cfg.bg = (int32_t)mxGetScalar(prhs[1]);
         cfg.Z = (int32_t)mxGetScalar(prhs[2]);
         cfg.max_iter = (int32_t)mxGetScalar(prhs[3]);                  // 'MaximumIterationCount', NRLDPCDecoder.m:41,120
@@ -78,13 +91,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         cfg.llr_dtype = NRLDPC_LLR_F64;                                // MATLAB doubles straight in
         nrldpc_handle h = nullptr;
         check(nrldpc_create(&cfg, &h));
-        if (g_handles.empty()) { mexLock(); mexAtExit(at_exit); }
+        if (registry_empty()) { mexLock(); mexAtExit(at_exit); }
         g_handles[g_next] = h;
         plhs[0] = mxCreateDoubleScalar((double)g_next++);
     } else if (!strcmp(cmd, "decode")) {
         need(nrhs == 3 && mxIsDouble(prhs[2]) && !mxIsComplex(prhs[2]), "decode needs a handle and a real double matrix.");
         nrldpc_handle h = handle_of(prhs[1]);
         nrldpc_dims d;
+        d.struct_size = sizeof d;
         check(nrldpc_get_dims(h, &d));
         need((int)mxGetM(prhs[2]) == d.N_cw, "cw_tilde should have N+2*Z_c rows.");
         const int C = (int)mxGetN(prhs[2]);
@@ -99,6 +113,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         need(nrhs == 3 && mxIsDouble(prhs[2]) && !mxIsComplex(prhs[2]), "encode needs a handle and a real double matrix.");
         nrldpc_handle h = handle_of(prhs[1]);
         nrldpc_dims d;
+        d.struct_size = sizeof d;
         check(nrldpc_get_dims(h, &d));
         need((int)mxGetM(prhs[2]) == d.K, "c should have K rows.");
         const int C = (int)mxGetN(prhs[2]);
@@ -125,7 +140,57 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (it != g_handles.end()) {
             nrldpc_destroy(it->second);
             g_handles.erase(it);
-            if (g_handles.empty()) mexUnlock();
+            if (registry_empty()) mexUnlock();
+        }
+    } else if (!strcmp(cmd, "pool_create")) {
+        need(nrhs >= 5 && mxIsDouble(prhs[4]), "pool_create needs BG, Z_c, iterations and a vector of device ordinals.");
+        nrldpc_cfg cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.struct_size = sizeof cfg;
+        cfg.bg = (int32_t)mxGetScalar(prhs[1]);
+        cfg.Z = (int32_t)mxGetScalar(prhs[2]);
+        cfg.max_iter = (int32_t)mxGetScalar(prhs[3]);
+        cfg.n_layers = nrhs > 6 ? (int32_t)mxGetScalar(prhs[6]) : 0;
+        cfg.early_term = 1;                                            // 'Parity check satisfied', NRLDPCDecoder.m:120
+        cfg.llr_dtype = NRLDPC_LLR_F64;
+        const size_t nd = mxGetNumberOfElements(prhs[4]);
+        need(nd >= 1 && nd <= 64, "between 1 and 64 device ordinals.");
+        std::vector<int32_t> ids(nd);
+        for (size_t i = 0; i < nd; ++i) ids[i] = (int32_t)mxGetPr(prhs[4])[i];
+        const int32_t chunks = nrhs > 5 ? (int32_t)mxGetScalar(prhs[5]) : 3;
+        Pool pl;
+        pl.p = nullptr;
+        check(nrldpc_pool_create(&cfg, ids.data(), (int32_t)nd, chunks, &pl.p));
+        // dimensions of the code: from a throw-away handle on the first device of the pool
+        cfg.device_id = ids[0];
+        nrldpc_handle h = nullptr;
+        int rc = nrldpc_create(&cfg, &h);
+        if (rc == NRLDPC_OK) { pl.d.struct_size = sizeof pl.d; rc = nrldpc_get_dims(h, &pl.d); nrldpc_destroy(h); }
+        if (rc != NRLDPC_OK) { nrldpc_pool_destroy(pl.p); check(rc); }
+        if (registry_empty()) { mexLock(); mexAtExit(at_exit); }
+        g_pools[g_next] = pl;
+        plhs[0] = mxCreateDoubleScalar((double)g_next++);
+    } else if (!strcmp(cmd, "pool_decode")) {
+        need(nrhs == 3 && mxIsDouble(prhs[2]) && !mxIsComplex(prhs[2]), "pool_decode needs a pool id and a real double matrix.");
+        auto pit = g_pools.find((uint64_t)mxGetScalar(prhs[1]));
+        need(pit != g_pools.end(), "unknown or released pool.");
+        const nrldpc_dims& d = pit->second.d;
+        need((int)mxGetM(prhs[2]) == d.N_cw, "cw_tilde should have N+2*Z_c rows.");
+        const int C = (int)mxGetN(prhs[2]);
+        std::vector<uint8_t> hard((size_t)d.K * (size_t)(C > 0 ? C : 1));
+        mxArray* it = mxCreateNumericMatrix(C, 1, mxINT32_CLASS, mxREAL);
+        check(nrldpc_pool_decode(pit->second.p, mxGetPr(prhs[2]), C, hard.data(), (int32_t*)mxGetData(it)));
+        plhs[0] = mxCreateDoubleMatrix(d.K, C, mxREAL);
+        double* o = mxGetPr(plhs[0]);
+        for (size_t i = 0; i < (size_t)d.K * C; ++i) o[i] = (double)hard[i];
+        if (nlhs > 1) plhs[1] = it; else mxDestroyArray(it);
+    } else if (!strcmp(cmd, "pool_destroy")) {
+        need(nrhs == 2, "pool_destroy needs a pool id.");
+        auto pit = g_pools.find((uint64_t)mxGetScalar(prhs[1]));
+        if (pit != g_pools.end()) {
+            nrldpc_pool_destroy(pit->second.p);
+            g_pools.erase(pit);
+            if (registry_empty()) mexUnlock();
         }
     } else {
         mexErrMsgIdAndTxt("ldpc_3gpp_matlab:Error", "unknown command '%s'.", cmd);

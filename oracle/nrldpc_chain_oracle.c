@@ -6,6 +6,8 @@
  *   orc_rate_recover : NRLDPCDecoder.m:143-169 (code_block_concatenation), :172-197 (bit_interleaving),
  *                      :200-242 (bit_selection incl. HARQ soft buffer) and :262-264 (2Z zero prefix, NaN -> +inf),
  *                      in fp32 with the reference's accumulation order (k ascending).
+ *   orc_rate_match   : NRLDPCEncoder.m:168-196 (bit_selection, NaN fillers skipped), :199-226 (bit_interleaving) and
+ *                      :229-256 (code_block_concatenation): the transmit-side tail, for the randomized testbench.m sweep.
  *   orc_crc          : comm.CRCGenerator / comm.CRCDetector semantics (zero initial state, no reflection, no
  *                      final XOR) for the polynomials of get_3gpp_crc_polynomial.m:3-14, bit-serial.
  * PARITY STATUS: these stages are pinned against the reference's own loops line by line; the only numeric
@@ -55,6 +57,34 @@ int orc_rate_recover(int Z, int C, int K, int K_prime, int N, int N_cb, int k_0,
         }
     }
     free(f); free(e); free(d); free(nan_);
+    return 0;
+}
+
+/* cw: [n_tb*C][2Z + N] encoded code blocks (bytes 0/1); positions [K'-2Z, K-2Z) of d = cw[2Z:] are fillers (NaN in the
+ * reference, NRLDPCEncoder.m:160).  g: [n_tb][G]. */
+int orc_rate_match(int Z, int C, int K, int K_prime, int N, int N_cb, int k_0, int Q_m, int G, const int32_t* E_r,
+                   const uint8_t* cw, int n_tb, uint8_t* g) {
+    const int ncwz = 2 * Z + N;
+    uint8_t* e = (uint8_t*)malloc((size_t)(G > 0 ? G : 1));
+    uint8_t* f = (uint8_t*)malloc((size_t)(G > 0 ? G : 1));
+    int lo = K_prime - 2 * Z; if (lo < 0) lo = 0;
+    for (int tb = 0; tb < n_tb; ++tb) {
+        int kg = 0;
+        for (int r = 0; r < C; ++r) {
+            const uint8_t* d = cw + ((size_t)tb * C + r) * ncwz + 2 * Z;
+            const int E = E_r[r];
+            int k = 0, j = 0; /* :186-195 */
+            while (k < E) {
+                const int pos = (k_0 + j) % N_cb;
+                if (!(pos >= lo && pos < K - 2 * Z)) { e[k] = d[pos]; ++k; }
+                ++j;
+            }
+            for (int jj = 0; jj < E / Q_m; ++jj) /* :219-223 */
+                for (int i = 0; i < Q_m; ++i) f[i + jj * Q_m] = e[i * (E / Q_m) + jj];
+            for (int q = 0; q < E; ++q) g[(size_t)tb * G + kg++] = f[q]; /* :243-253 */
+        }
+    }
+    free(e); free(f);
     return 0;
 }
 

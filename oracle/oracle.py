@@ -38,6 +38,7 @@ def lib():
         L.orc_decode_bp_flood_app.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32, P]
         L.orc_set_threads.argtypes = [i32]
         L.orc_rate_recover.argtypes = [i32] * 9 + [P, P, i32, P, P]
+        L.orc_rate_match.argtypes = [i32] * 9 + [P, P, i32, P]
         L.orc_crc.argtypes = [C.c_uint32, i32, P, i32]
         L.orc_crc.restype = C.c_uint32
         _LIB = L
@@ -115,6 +116,17 @@ def rate_recover(Z, C_, K, K_prime, N, N_cb, k_0, Q_m, G, E_r, g_tilde, harq=Non
     rc = lib().orc_rate_recover(Z, C_, K, K_prime, N, N_cb, k_0, Q_m, G, _p(E), _p(g_tilde), n_tb, _p(harq), _p(out))
     assert rc == 0
     return out
+
+
+def rate_match(Z, C_, K, K_prime, N, N_cb, k_0, Q_m, G, E_r, cw):
+    """Literal NRLDPCEncoder.m:168-256; cw: [n_tb*C][2Z+N] bytes -> [n_tb][G] bytes."""
+    cw = np.ascontiguousarray(cw, np.uint8).reshape(-1, 2 * Z + N)
+    n_tb = cw.shape[0] // C_
+    E = np.ascontiguousarray(E_r, np.int32)
+    g = np.zeros((n_tb, G), np.uint8)
+    rc = lib().orc_rate_match(Z, C_, K, K_prime, N, N_cb, k_0, Q_m, G, _p(E), _p(cw), n_tb, _p(g))
+    assert rc == 0
+    return g
 
 
 def crc(poly, L, bits):

@@ -108,3 +108,37 @@ def test_matlab_patch_applies(tmp_path):
     dec = (tmp_path / "NRLDPCDecoder.m").read_text(encoding="latin-1")
     assert "nrldpc_mex('decode', obj.hLDPCDecoder, cw_tilde)" in dec and "comm.LDPCDecoder(" not in dec
     assert "nrldpc_mex('encode'" in (tmp_path / "NRLDPCEncoder.m").read_text(encoding="latin-1")
+    enc = (tmp_path / "NRLDPCEncoder.m").read_text(encoding="latin-1")
+    assert enc.count("releaseImpl") == 1 and dec.count("function releaseImpl") == 1  # both objects give their codec back
+
+
+def test_mex_gateway_compiles_against_the_stub_mex_api():
+    """matlab/nrldpc_mex.cpp cannot be built into a MEX file here (no MATLAB); it is compile-checked against
+    tests/mex_stub/mex.h (declarations of the documented MEX API calls it uses) with warnings as errors, so that a
+    change of include/nrldpc.h that breaks the gateway is caught on the CPU."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                           "-I" + os.path.join(ROOT, "tests", "mex_stub"), "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "matlab", "nrldpc_mex.cpp")])
+    src = open(os.path.join(ROOT, "matlab", "nrldpc_mex.cpp")).read()
+    for cmd in ("create", "decode", "encode", "destroy", "default_rule", "pool_create", "pool_decode", "pool_destroy"):
+        assert '"%s"' % cmd in src, cmd
+
+
+def test_abi_revision_and_struct_size_guard(pkg):
+    """ABI revision 3: nrldpc_cfg / nrldpc_dims carry their size; a caller built against another revision is refused
+    instead of having memory past its struct read or written."""
+    C = pkg._capi
+    lib = pkg.load()
+    assert lib.nrldpc_abi_version() == C.ABI_VERSION == 3
+    hdr = open(os.path.join(ROOT, "include", "nrldpc.h")).read()
+    assert "#define NRLDPC_ABI_VERSION 3" in hdr
+    cfg = C.Cfg(1, 384, 0, 10, 1, 0.0, 0, 0, 0, 0)
+    assert cfg.struct_size == ctypes.sizeof(C.Cfg)
+    cfg.struct_size = ctypes.sizeof(C.Cfg) - 4  # the r1 layout (no beta)
+    h = ctypes.c_void_p()
+    assert lib.nrldpc_create(ctypes.byref(cfg), ctypes.byref(h)) == C.ERR_ARG and h.value is None
+    assert b"struct_size" in lib.nrldpc_last_error()

@@ -30,4 +30,4 @@ for bg in (1, 2):
         print("BG%d Z=%3d batch %6d: %.3f ms  %.2f Gbit/s info  %.1f edge-updates/ns" % (bg, Z, B, t, rec["info_Gbit_s"], rec["edge_updates_per_ns"]), flush=True)
         del llr, hard
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_all_z.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_all_z%s.json" % os.environ.get("OUT_SUFFIX", "")), "w"), indent=1)

@@ -118,7 +118,7 @@ def main():
     out.append(run("cfg5 BG1 Z=384 R=8/9 early stop, 8192 codewords (one GPU's shard of 65536)", 1, 384, 8192, 9478, 5, 25, 1, 7.5))
     out.append(run("cfg5 worst case: no early stop", 1, 384, 8192, 9478, 5, 25, 0, 7.5))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs%s.json" % os.environ.get("OUT_SUFFIX", "")), "w"), indent=1)
 
 
 if __name__ == "__main__":
