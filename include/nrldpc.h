@@ -52,7 +52,8 @@ typedef struct nrldpc_codec* nrldpc_handle;
 
 /* ABI revision of this header.  Revision 3 put `struct_size` in front of nrldpc_cfg and nrldpc_dims (revision 2 had
  * grown both at the tail -- beta; alpha, beta -- with nothing a caller built against revision 1 could be told apart by).
- * nrldpc_abi_version() returns the revision the loaded library was built with; the library's SONAME carries it too. */
+ * nrldpc_abi_version() returns the revision the loaded library was built with (the library is loaded by path and has
+ * no SONAME; a binding checks this number at load time, as ldpc-3gpp-matlab_amd/_capi.py does). */
 #define NRLDPC_ABI_VERSION 3
 
 typedef struct nrldpc_cfg {
@@ -218,6 +219,8 @@ const char* nrldpc_strerror(int code);
 const char* nrldpc_last_error(void); /* text of the most recent failure on this thread */
 const char* nrldpc_version(void);
 const char* nrldpc_build_id(void);   /* hash of the sources this binary was built from (build.py: source_id) */
+const char* nrldpc_kernel_id(void);  /* hash of the decoder kernels' sources alone (build.py: kernel_id): ties a rocprofv3
+                                        summary under profiles/ to the kernels it measured */
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,7 @@ def tb_params(p):
 EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev", "nrldpc_crc_check_dev", "nrldpc_crc_check_harq_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
            "nrldpc_decode_multi_dev", "nrldpc_quantise_llr", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
-           "nrldpc_version", "nrldpc_build_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
+           "nrldpc_version", "nrldpc_build_id", "nrldpc_kernel_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
            "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version"]
 
 _lib = None
@@ -108,6 +108,7 @@ def load():
                 path = _build.build_lib()
     L = C.CDLL(path)
     L.nrldpc_build_id.restype = C.c_char_p
+    L.nrldpc_kernel_id.restype = C.c_char_p
     if not os.environ.get("NRLDPC_LIB") and L.nrldpc_build_id().decode() != _build.source_id():
         raise RuntimeError("libnrldpc_hip.so (build %s) does not match the sources in the tree (%s) and could not be "
                            "rebuilt" % (L.nrldpc_build_id().decode(), _build.source_id()))

@@ -12,8 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip.so")  # env override: kernel experiments
-OBJDIR = os.path.join(HERE, "build")
+# NRLDPC_BUILD_AB=1: the A/B build -- both decoder forms (one / two threads per row) for every (BG, Z), chosen at run time by
+# NRLDPC_SPLIT=0/1 -- into its own library and object directory; load it with NRLDPC_LIB=<path> (tools/forms_session.sh)
+AB = bool(os.environ.get("NRLDPC_BUILD_AB"))
+LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip_ab.so" if AB else "libnrldpc_hip.so")  # env override: kernel experiments
+OBJDIR = os.path.join(HERE, "build_ab" if AB else "build")
 SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_channel.hip",
            "nrldpc_expand.hip", "nrldpc_capi.hip", "nrldpc_host_quant.cpp"]  # .cpp: host-only C++ (no device pass)
 Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
@@ -24,7 +27,7 @@ Z64_PAIRS = [(1, z) for z in Z64_BG1] + [(2, z) for z in Z64_BG2]
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7)]
 HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_wave.h", "nrldpc_host_quant.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DNRLDPC_Z64_AB"] if AB else [])
 
 
 def _hipcc():
@@ -51,6 +54,24 @@ def source_id():
     return h.hexdigest()[:16]
 
 
+KERNEL_SOURCES = ["nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64_inst.hip", "nrldpc_decode.hip",
+                  "nrldpc_device.h", "nrldpc_kernels.h"]
+
+
+def kernel_id():
+    """Hash of what the DECODER kernels are compiled from (their sources, the base-graph tables, the compiler flags):
+    nrldpc_kernel_id() of the library.  rocprofv3 summaries under profiles/ carry it, and bench.py uses a summary's
+    instruction counts only when it equals the loaded library's -- a kernel change without a profile refresh cannot
+    silently falsify the roofline fractions, while a change elsewhere (C ABI, Python) does not invalidate a profile."""
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, f) for f in KERNEL_SOURCES] + [os.path.join(INCLUDE, "nr_bg_tables.h")]:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     """The library is missing, or was built from other sources than the ones in the tree now."""
     if not os.path.exists(LIB):
@@ -71,22 +92,48 @@ def build_lib(force=False, verbose=False, jobs=None):
     os.makedirs(OBJDIR, exist_ok=True)
     inc = ["-I" + INCLUDE, "-I" + CSRC]
     units = [(os.path.join(CSRC, f), os.path.join(OBJDIR, os.path.splitext(f)[0] + ".o"),
-              ['-DNRLDPC_BUILD_ID="%s"' % sid] if f == "nrldpc_capi.hip" else []) for f in SOURCES]
+              ['-DNRLDPC_BUILD_ID="%s"' % sid, '-DNRLDPC_KERNEL_ID="%s"' % kernel_id()] if f == "nrldpc_capi.hip" else [])
+             for f in SOURCES]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d.o" % (bg, z)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64_PAIRS]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64_NL]
-    newest = max(os.path.getmtime(d) for d in _deps())
+    # An object is reused only when it was compiled from exactly these inputs: contents of its source and of every
+    # header, the flags and the -D list (sidecar <obj>.id) -- never by modification time, which a snapshot copy, rsync -t
+    # or tar may set to anything.  nrldpc_capi carries the build id of the whole tree, so it is keyed by that as well.
+    hh = hashlib.sha256()
+    for d in sorted(_deps()):
+        if not d.endswith((".hip", ".cpp")):
+            with open(d, "rb") as f:
+                hh.update(os.path.basename(d).encode() + b"\0" + f.read())
+    headers_id = hh.hexdigest()
+
+    def unit_id(src, flags, defs):
+        h = hashlib.sha256()
+        with open(src, "rb") as f:
+            h.update(f.read())
+        h.update(("\0".join([headers_id, *flags, *defs])).encode())
+        return h.hexdigest()[:24]
 
     def compile_one(u):
         src, obj, defs = u
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest and not src.endswith("nrldpc_capi.hip"):
-            return obj
         flags = [f for f in FLAGS if not f.startswith("--offload-arch")] if src.endswith(".cpp") else FLAGS
+        uid = unit_id(src, flags, defs)
+        try:
+            with open(obj + ".id") as f:
+                fresh = os.path.exists(obj) and f.read().strip() == uid
+        except OSError:
+            fresh = False
+        if fresh and not force:
+            return obj
         cmd = [hipcc, *flags, *inc, *defs, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
+        if os.path.exists(obj + ".id"):
+            os.remove(obj + ".id")
         subprocess.check_call(cmd)
+        with open(obj + ".id", "w") as f:
+            f.write(uid + "\n")
         return obj
 
     jobs = jobs or min(len(units), max(1, (os.cpu_count() or 2)))

@@ -482,6 +482,10 @@ int nrldpc_abi_version(void) { return NRLDPC_ABI_VERSION; }
 #define NRLDPC_BUILD_ID "unknown"
 #endif
 const char* nrldpc_build_id(void) { return NRLDPC_BUILD_ID; }
+#ifndef NRLDPC_KERNEL_ID
+#define NRLDPC_KERNEL_ID "unknown"
+#endif
+const char* nrldpc_kernel_id(void) { return NRLDPC_KERNEL_ID; }
 
 int nrldpc_default_rule(int32_t bg, int32_t n_layers, float* alpha, float* beta) {
     if (bg != 1 && bg != 2) return fail(NRLDPC_ERR_UNSUPPORTED, "BG must be 1 or 2");
@@ -1110,7 +1114,9 @@ int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, i
     if (rc) return rc;
     if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
     if (n_tb == 0) return NRLDPC_OK;
-    if (!d_g_tilde || !d_cw_llr) return fail(NRLDPC_ERR_ARG, "null pointer");
+    // G == 0 is a legal draw of the reference's own sweep (testbench.m:35 with a small A): nothing was transmitted, the
+    // decoder input is all zeros / fillers, and an empty g_tilde has no address
+    if ((!d_g_tilde && p->G > 0) || !d_cw_llr) return fail(NRLDPC_ERR_ARG, "null pointer");
     if (out_dtype != NRLDPC_LLR_F32 && out_dtype != NRLDPC_LLR_F16) return fail(NRLDPC_ERR_ARG, "out_dtype must be f32 or f16");
     nrldpc::RmArgs a;
     a.g = d_g_tilde; a.harq = d_harq; a.out = d_cw_llr; a.out_f16 = out_dtype == NRLDPC_LLR_F16;
@@ -1190,6 +1196,7 @@ int nrldpc_rate_match_dev(const nrldpc_tb_params* p, const uint8_t* d_cw, int32_
     if (rc) return rc;
     if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
     if (n_tb == 0) return NRLDPC_OK;
+    if (p->G == 0) return NRLDPC_OK; // nothing to transmit (testbench.m:35 can draw G = 0); g has no address then
     if (!d_cw || !d_g) return fail(NRLDPC_ERR_ARG, "null pointer");
     nrldpc::TxRmArgs a;
     a.cw = d_cw; a.g = d_g; a.n_tb = n_tb; a.C = p->C; a.G = p->G; a.Z = p->Z; a.K = p->K; a.Kp = p->K_prime;

@@ -881,37 +881,64 @@ static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
 #include "nrldpc_decode_z64s.h" // the two-threads-per-row form of the same decoder
 namespace nrldpc {
 
-// Which form serves a (BG, Z, layer count): NRLDPC_SPLIT=0 / 1 in the environment forces one (A/B on the MI355X:
-// tools/bench_all_z.py); otherwise z64_split_default, the measured choice.
-inline int split_env() {
-    static const int v = getenv("NRLDPC_SPLIT") ? atoi(getenv("NRLDPC_SPLIT")) : -1;
-    return v;
-}
+// Which form serves a (BG, Z, layer count): the measured choice, z64_split_default -- both forms timed on the MI355X for
+// every pair at 25 fixed iterations and for every BASELINE configuration (profiles/r03_forms_all_z.json,
+// r03_forms_configs.json).  The split form wins where two of its workgroups (or more) fill a CU's wave slots evenly:
+// BG1 +5...16 % (Z = 384: +11 %, 288: +16 %), small BG2 sizes +12...26 %; it loses where a workgroup of 2 Z/B waves leaves
+// slots empty (Z = 320: 10-wave workgroups, Z = 352: 16) or spreads unevenly over the 4 SIMDs (6-wave workgroups, Z = 144,
+// 192), and on BG2 Z = 384, whose one-thread-per-row form already runs 6 waves per SIMD with four codewords per CU.
+// A library built with -DNRLDPC_Z64_AB carries both forms for every pair and takes NRLDPC_SPLIT=0 / 1 from the
+// environment (the A/B build of those measurements); the shipped build compiles only the form it uses.
 template <int BG, int ZC, int NL> constexpr bool z64_split_default() {
 #ifdef NRLDPC_Z64_SPLIT
     return NRLDPC_Z64_SPLIT != 0;
 #endif
-    return BG == 1 && ZC == 384 && NL == BGT<BG>::ROWS;
+    if (NL != BGT<BG>::ROWS) return BG == 1 && ZC == 384 && NL <= 6; // the R = 8/9 shard of BASELINE configs[4]
+    if (BG == 1)
+        return ZC == 60 || ZC == 64 || ZC == 104 || ZC == 112 || ZC == 120 || ZC == 128 || ZC == 176 || ZC == 208 || ZC == 224 ||
+               ZC == 240 || ZC == 256 || ZC == 288 || ZC == 384;
+    return ZC == 52 || ZC == 60 || ZC == 64 || ZC == 208 || ZC == 224 || ZC == 240 || ZC == 256;
 }
-template <int BG, int ZC, int NL> static bool use_split() {
+#ifdef NRLDPC_Z64_AB
+constexpr bool z64_ab = true;
+#else
+constexpr bool z64_ab = false;
+#endif
+inline int split_env() {
+    static const int v = getenv("NRLDPC_SPLIT") ? atoi(getenv("NRLDPC_SPLIT")) : -1;
+    return v;
+}
+template <int BG, int ZC, int NL> constexpr bool z64_has_split() {
     if constexpr (!Z64S<BG, ZC, NL>::usable()) return false;
-    const int e = split_env();
-    return e < 0 ? z64_split_default<BG, ZC, NL>() : e != 0;
+    else return z64_ab || z64_split_default<BG, ZC, NL>();
+}
+template <int BG, int ZC, int NL> constexpr bool z64_has_row() { return z64_ab || !z64_has_split<BG, ZC, NL>(); }
+template <int BG, int ZC, int NL> static bool use_split() {
+    if constexpr (!z64_has_split<BG, ZC, NL>()) return false;
+    else if constexpr (!z64_has_row<BG, ZC, NL>()) return true;
+    else {
+        const int e = split_env();
+        return e < 0 ? z64_split_default<BG, ZC, NL>() : e != 0;
+    }
 }
 
 // the pipelined pair (fixed iteration count / early termination) for a compile-time pruned layer count: its own
 // translation unit (nrldpc_decode_z64_inst.hip with -DNRLDPC_Z64_NL=<count>)
 template <int BG, int ZC, int NCWG, int NL> static hipError_t launch_z64_pruned(const DecArgs& a, hipStream_t s) {
-    if constexpr (Z64S<BG, ZC, NL>::usable()) {
+    if constexpr (z64_has_split<BG, ZC, NL>()) {
         if (use_split<BG, ZC, NL>()) return a.early_term ? launch_z64s<BG, ZC, true, NL>(a, s) : launch_z64s<BG, ZC, false, NL>(a, s);
     }
-    if (a.early_term) return launch_z64f<BG, ZC, NCWG, true, false, true, NL>(a, s);
-    return launch_z64f<BG, ZC, NCWG, true, true, false, NL>(a, s);
+    if constexpr (z64_has_row<BG, ZC, NL>()) {
+        if (a.early_term) return launch_z64f<BG, ZC, NCWG, true, false, true, NL>(a, s);
+        return launch_z64f<BG, ZC, NCWG, true, true, false, NL>(a, s);
+    }
+    return hipErrorUnknown; // not reached: one of the two forms exists
 }
 
 template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
-    if constexpr (Z64S<BG, ZC, BGT<BG>::ROWS>::usable()) {
-        if (a.n_layers == BGD<BG>::ROWS && !a.app && use_split<BG, ZC, BGT<BG>::ROWS>())
+    constexpr int ROWS = BGT<BG>::ROWS;
+    if constexpr (z64_has_split<BG, ZC, ROWS>()) {
+        if (a.n_layers == ROWS && !a.app && use_split<BG, ZC, ROWS>())
             return a.early_term ? launch_z64s<BG, ZC, true>(a, s) : launch_z64s<BG, ZC, false>(a, s);
     }
     static const bool no_pruned = getenv("NRLDPC_NO_PRUNED_PIPELINE") != nullptr; // A/B against the general kernel
@@ -923,9 +950,12 @@ template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& 
 #undef NRLDPC_Z64_NL_CASE
     }
     // other pruned layer counts and soft output (a test / debug feature) share the unpipelined general kernel
-    if (a.n_layers != BGD<BG>::ROWS || a.app) return launch_z64f<BG, ZC, NCWG, false, false>(a, s);
-    if (a.early_term) return launch_z64f<BG, ZC, z64_ncwg_et<BG, ZC>(), true, false, true>(a, s);
-    return launch_z64f<BG, ZC, NCWG, true, true>(a, s);
+    if (a.n_layers != ROWS || a.app) return launch_z64f<BG, ZC, NCWG, false, false>(a, s);
+    if constexpr (z64_has_row<BG, ZC, ROWS>()) {
+        if (a.early_term) return launch_z64f<BG, ZC, z64_ncwg_et<BG, ZC>(), true, false, true>(a, s);
+        return launch_z64f<BG, ZC, NCWG, true, true>(a, s);
+    }
+    return hipErrorUnknown; // not reached
 }
 
 } // namespace nrldpc

@@ -151,12 +151,14 @@ __global__ __launch_bounds__(256) void nrldpc_rate_recover_fast_kernel(const RmA
             idx[t] = live[t] ? j * QM + i : 0;
             pp[t] = inbuf ? p : -1;
         }
-        v[0] = f[idx[0]];
-        v[1] = f[idx[1]];
+        // predicated: a position that receives nothing must not touch g_tilde at all -- for a trailing code block with
+        // E_r == 0 (not retransmitted under CBGTI) f already points one past the transport block's LLRs
+        v[0] = live[0] ? f[idx[0]] : 0.0f;
+        v[1] = live[1] ? f[idx[1]] : 0.0f;
         OutT o[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            float val = live[t] ? v[t] : 0.0f;
+            float val = v[t];
             if (hb && pp[t] >= 0) { // :236-239
                 val += hb[pp[t]];
                 hb[pp[t]] = val;

@@ -118,11 +118,15 @@ class NRLDPCDecoder(NRLDPC):
         else:
             self.validate()
             if g_tilde.shape[0] != self._nb:
-                if (self.code_block_CRC_passed is not None and self.code_block_CRC_passed.any()) or \
-                        (self.I_HARQ != 0 and self.d_tilde_buffer is not None and self.d_tilde_buffer.any()):
-                    # the reference never drops HARQ / CRC state without an explicit reset()
-                    raise NRLDPCError("batch size changed from %d to %d transport blocks with decoder state pending; "
-                                      "call reset() first." % (self._nb, g_tilde.shape[0]))
+                # A batch of n transport blocks stands for n reference objects.  With I_HARQ ~= 0 those objects carry
+                # soft buffers and CRC flags from step to step (NRLDPCDecoder.m:236-239, 286-314): a different batch size
+                # with such state pending is an error, never a silent drop.  With I_HARQ == 0 nothing of a step is
+                # used by the next one except the sticky pass flags, which say nothing about a different set of
+                # transport blocks: a new batch size simply starts a new set.
+                if self.I_HARQ != 0 and ((self.code_block_CRC_passed is not None and self.code_block_CRC_passed.any()) or
+                                         (self.d_tilde_buffer is not None and self.d_tilde_buffer.any())):
+                    raise NRLDPCError("batch size changed from %d to %d transport blocks with HARQ state pending "
+                                      "(I_HARQ ~= 0); call reset() first." % (self._nb, g_tilde.shape[0]))
                 self._nb = g_tilde.shape[0]
                 self.reset()
         d_tilde = self.rate_recover(g_tilde)

@@ -67,9 +67,12 @@ class DeviceDecodeChain:
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         ncwz = 2 * p.Z_c + p.N
         if self.cb_pass is not None and self.cb_pass.shape[0] != n_tb:
-            # the reference never drops HARQ / CRC state without an explicit reset(): a different batch size is an error
-            raise NRLDPCError("batch size changed from %d to %d transport blocks with decoder state pending; call "
-                              "reset() first." % (self.cb_pass.shape[0], n_tb))
+            # see NRLDPCDecoder.step_batch: only HARQ state that is really pending makes a new batch size an error
+            # (the check synchronises, but only on this rare path); without it a new batch size starts a new set
+            if self.I_HARQ and (bool(self.cb_pass.any()) or bool(self.harq.any())):
+                raise NRLDPCError("batch size changed from %d to %d transport blocks with HARQ state pending "
+                                  "(I_HARQ ~= 0); call reset() first." % (self.cb_pass.shape[0], n_tb))
+            self.cb_pass = self.b_hat = self.harq = None
         if self.cb_pass is None:
             self.cb_pass = torch.zeros((n_tb, C_), dtype=torch.int32, device=self.dev)
             self.b_hat = torch.zeros((n_tb, p.B), dtype=torch.uint8, device=self.dev)

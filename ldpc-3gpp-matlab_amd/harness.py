@@ -114,42 +114,90 @@ def demodulate_llr_t(rx, Q_m, N0):
     return out.reshape(rx.shape[:-1] + (-1,))
 
 
-def simulate_point_device(enc_chain, dec_chain, Q_m, EsN0, rv_id_sequence, batch, gen, chan=None):
-    """simulate_point with every stage on the GPU (rows N1-N4 of SURVEY.md section 8f): payload RNG, CRC
-    attachment, encoding, rate matching, modulation + AWGN + exact LLRs (one HIP kernel, nrldpc_awgn_llr_dev),
-    rate recovery, decoding, CRC check, error count.  enc_chain / dec_chain share one NRLDPC parameter object.
-    chan: [seed, symbols drawn so far] of the channel's counter-based noise generator (advanced here)."""
+_SM64 = (0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB)
+
+
+def payload_bits_np(seed, first_block, n, A):
+    """Payload of transport blocks first_block .. first_block+n-1 (numpy restatement of payload_bits): bit i of block b is
+    the top bit of splitmix64(seed + (b*A + i) * golden) -- a function of the GLOBAL block index only, so any split of a
+    batch over devices draws the same payloads (the reference draws round(rand(A,1)) per block, plot_BLER_vs_SNR.m:118)."""
+    idx = (np.arange(first_block, first_block + n, dtype=np.uint64)[:, None] * np.uint64(A) + np.arange(A, dtype=np.uint64)[None, :])
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed % (1 << 64)) + (idx + np.uint64(1)) * np.uint64(_SM64[0])
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(_SM64[1])
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(_SM64[2])
+        x = x ^ (x >> np.uint64(31))
+    return (x >> np.uint64(63)).astype(np.uint8)
+
+
+def payload_bits(seed, first_block, n, A, dev):
+    """The same on the device (int64 arithmetic wraps like uint64; right shifts made logical by masking)."""
+    import torch
+    s64 = lambda c: c - (1 << 64) if c >= (1 << 63) else c
+    lsr = lambda x, k: (x >> k) & ((1 << (64 - k)) - 1)
+    idx = (torch.arange(first_block, first_block + n, device=dev, dtype=torch.int64)[:, None] * A
+           + torch.arange(A, device=dev, dtype=torch.int64)[None, :])
+    x = (idx + 1) * s64(_SM64[0]) + s64(seed % (1 << 64))
+    x = (x ^ lsr(x, 30)) * s64(_SM64[1])
+    x = (x ^ lsr(x, 27)) * s64(_SM64[2])
+    x = x ^ lsr(x, 31)
+    return lsr(x, 63).to(torch.uint8)
+
+
+ATTEMPT_STRIDE = 1 << 40  # Philox symbol counter = attempt * 2^40 + global block index * symbols per block + symbol
+
+
+def simulate_point_device(chains, Q_m, EsN0, rv_id_sequence, batch, seed, first_block):
+    """simulate_point with every stage on the GPU(s) (rows N1-N4 of SURVEY.md section 8f): payload, CRC attachment,
+    encoding, rate matching, modulation + AWGN + exact LLRs (one HIP kernel, nrldpc_awgn_llr_dev), rate recovery, decoding,
+    CRC check, error count.
+
+    chains: one (DeviceEncodeChain, DeviceDecodeChain) pair per shard -- one per GPU of the node, or several on one GPU.
+    The batch of `batch` transport blocks with GLOBAL indices first_block .. first_block+batch-1 is dealt to the shards
+    in contiguous slices; payload bits and channel noise are functions of (seed, global block index, attempt) alone, so
+    the outcome vector -- and the result file plot_BLER_vs_SNR writes from it -- is identical for 1, 2, 4 or 8 shards:
+    the reference's "parallel instances ... aggregated together" (plot_BLER_vs_SNR.m:23-27) without the manual step,
+    and without any collective (transport blocks are independent).  Work of all shards is launched before the first
+    synchronisation, so GPUs run concurrently under one host thread."""
     import torch
     from ._capi import awgn_llr_dev
-    p = enc_chain.p
-    dev = enc_chain.dev
-    a = torch.randint(0, 2, (batch, p.A), generator=gen, device=dev, dtype=torch.uint8)   # :118
+    D = len(chains)
+    cuts = [batch * i // D for i in range(D + 1)]
     N0 = 1.0 / 10.0 ** (EsN0 / 10.0)
-    ok = torch.zeros(batch, dtype=torch.bool, device=dev)
-    a_hat = torch.zeros((batch, p.A), dtype=torch.uint8, device=dev)
-    dec_chain.reset()                                                                      # :122
+    st = []
+    for d, (enc_chain, dec_chain) in enumerate(chains):
+        n = cuts[d + 1] - cuts[d]
+        p, dev = enc_chain.p, enc_chain.dev
+        with torch.cuda.device(dev):
+            a = payload_bits(seed, first_block + cuts[d], n, p.A, dev)                     # :118
+            st.append(dict(a=a, ok=torch.zeros(n, dtype=torch.bool, device=dev), n=n, live=n > 0,
+                           a_hat=torch.zeros((n, p.A), dtype=torch.uint8, device=dev)))
+            if n:
+                dec_chain.reset()                                                          # :122
     for n_rv, rv in enumerate(rv_id_sequence):                                             # :124-137
-        p.rv_id = rv
-        g = enc_chain.step(a)
-        if chan is not None:                                                               # :130-132 in one kernel
-            g_tilde = torch.empty(g.shape, dtype=torch.float32, device=dev)
+        for d, (enc_chain, dec_chain) in enumerate(chains):
+            s = st[d]
+            if not s["live"]:
+                continue
+            p, dev = enc_chain.p, enc_chain.dev
+            p.rv_id = rv
             with torch.cuda.device(dev):
-                awgn_llr_dev(g.data_ptr(), g.numel(), Q_m, EsN0, chan[0], chan[1], g_tilde.data_ptr(),
+                g = enc_chain.step(s["a"])
+                g_tilde = torch.empty(g.shape, dtype=torch.float32, device=dev)           # :130-132 in one kernel
+                first_symbol = n_rv * ATTEMPT_STRIDE + (first_block + cuts[d]) * (p.G // Q_m)
+                awgn_llr_dev(g.data_ptr(), g.numel(), Q_m, EsN0, seed, first_symbol, g_tilde.data_ptr(),
                              torch.cuda.current_stream(dev).cuda_stream)
-            chan[1] += g.numel() // Q_m
-        else:  # torch elementwise restatement (float64), kept as the cross-check of the kernel
-            tx = modulate_t(g, Q_m)
-            noise = (N0 / 2.0) ** 0.5 * torch.complex(
-                torch.randn(tx.shape, generator=gen, device=dev, dtype=torch.float64),
-                torch.randn(tx.shape, generator=gen, device=dev, dtype=torch.float64))
-            g_tilde = demodulate_llr_t(tx + noise, Q_m, N0).float()
-        dec, good, _ = dec_chain.step(g_tilde)
-        newly = good & ~ok
-        a_hat = torch.where(newly[:, None], dec, a_hat)  # (no boolean indexing: that is a host synchronisation per batch)
-        ok |= good
-        if n_rv + 1 < len(rv_id_sequence) and bool(ok.all()):  # the reference stops retransmitting once the block is in (:136)
-            break
-    return (ok & (a_hat == a).all(dim=1)).cpu().numpy()
+                dec, good, _ = dec_chain.step(g_tilde)
+                newly = good & ~s["ok"]
+                s["a_hat"] = torch.where(newly[:, None], dec, s["a_hat"])  # (no boolean indexing: a host sync per batch)
+                s["ok"] = s["ok"] | good
+        if n_rv + 1 < len(rv_id_sequence):  # a shard whose blocks are all in stops retransmitting (:136); one sync per attempt
+            for s in st:
+                s["live"] = s["live"] and not bool(s["ok"].all())
+            if not any(s["live"] for s in st):
+                break
+    out = [(s["ok"] & (s["a_hat"] == s["a"]).all(dim=1)).cpu().numpy() for s in st]
+    return np.concatenate(out) if out else np.zeros(0, bool)
 
 
 def _num2str(x):
@@ -187,9 +235,10 @@ def simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng):
 
 def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0,), iterations=8,
                      target_block_errors=3, target_BLER=1e-3, EsN0_start=0.0, EsN0_delta=0.5, seed=0,
-                     results_dir="results", batch=256, max_points=200, decoder_kwargs=None, device=False):
+                     results_dir="results", batch=256, max_points=200, decoder_kwargs=None, device=False, devices=None):
     """Same positional parameters and defaults as plot_BLER_vs_SNR.m:1,30-42 (no figure is drawn).
-    device=True keeps every stage on the GPU (simulate_point_device).
+    device=True keeps every stage on the GPU (simulate_point_device); devices = HIP ordinals of the shards (default [0];
+    an ordinal may repeat: logical shards on one GPU) -- the result file does not depend on their number.
     Returns {(A, R, BG): [(EsN0, BLER, blocks), ...]}."""
     rng = np.random.default_rng(seed)                                # :45
     Q_m = Q_M.get(Modulation)
@@ -213,23 +262,27 @@ def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0
                                          **(decoder_kwargs or {}))                                       # :99
                     hEnc.validate()
                     if device:
-                        import torch
                         from .device_chain import DeviceDecodeChain, DeviceEncodeChain
                         from .nrldpc import NRLDPC
-                        shared = NRLDPC(A=a_len, BG=bg, G=G, Q_m=Q_m)
-                        tx_chain = DeviceEncodeChain(shared)
-                        rx_chain = DeviceDecodeChain(shared, iterations=iterations, I_HARQ=1, **(decoder_kwargs or {}))
-                        gen = torch.Generator(device="cuda")
-                        gen.manual_seed(int(seed))
-                        chan = [int(seed) * 0x9E3779B97F4A7C15 % (1 << 64), 0]  # noise stream of this curve
+                        chains = []
+                        for ordinal in (devices or [0]):  # one parameter object and one chain pair per shard
+                            shared = NRLDPC(A=a_len, BG=bg, G=G, Q_m=Q_m)
+                            chains.append((DeviceEncodeChain(shared, device_id=int(ordinal)),
+                                           DeviceDecodeChain(shared, iterations=iterations, I_HARQ=1, device_id=int(ordinal),
+                                                             **(decoder_kwargs or {}))))
+                        curve_seed = int(seed) * 0x9E3779B97F4A7C15 % (1 << 64)  # payload / noise streams of this curve
+                        first_block = 0                                          # global index of the next transport block
                     with open(os.path.join(results_dir, name), "w") as fid:
                         BLER, EsN0, found_start = 1.0, float(EsN0_start), False                          # :84-88
                         while BLER > target_BLER and len(points) < max_points:                           # :104
                             blocks = errors = 0
                             keep_going = True
                             while keep_going and errors < target_block_errors:                           # :116
-                                outcomes = (simulate_point_device(tx_chain, rx_chain, Q_m, EsN0, rv_id_sequence, batch, gen, chan)
-                                            if device else simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng))
+                                if device:
+                                    outcomes = simulate_point_device(chains, Q_m, EsN0, rv_id_sequence, batch, curve_seed, first_block)
+                                    first_block += batch
+                                else:
+                                    outcomes = simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng)
                                 for good in outcomes:
                                     if not found_start and not good:                                     # :139-141
                                         keep_going, BLER = False, 1.0
@@ -248,8 +301,9 @@ def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0
                     hEnc.release()
                     hDec.release()
                     if device:
-                        tx_chain.close()
-                        rx_chain.close()
+                        for tx_chain, rx_chain in chains:
+                            tx_chain.close()
+                            rx_chain.close()
                 except UnsupportedParameters:                        # :172-176: skip this (A, R, BG)
                     continue
                 curves[(a_len, float(r), bg)] = points

@@ -11,6 +11,11 @@ IDENTICAL noise realisations at the same iteration cap over an Es/N0 grid; the t
 with both crossings interpolated on log10(BLER).  Round 1 measured +0.20 dB at the headline code with plain
 normalised min-sum; the offset rule of round 2 brings it to about +0.03 dB.  Results go to gpurun_out/bler_gap.json
 (DESIGN.md section 6 is regenerated from that file).
+
+Round 3: where the curve is steep.  For the headline code and cfg3 R = 1/3 a second crossing at
+BLER 1e-2 on 4096 blocks with its own stated bound (BOUND_DB_1E2), and -- recorded, NOT bounded -- the gap to the
+reference's DEFAULT of 50 sum-product sweeps (NRLDPCDecoder.m:41) at that BLER.  PARITY STATUS: all of this compares with a
+restatement of the reference's documented algorithm; the reference's own arithmetic is closed source (parity unpinned).
 """
 import json
 import os
@@ -25,6 +30,19 @@ pytestmark = pytest.mark.gpu
 
 BOUND_DB = 0.10  # stated bound at equal iteration caps, every BASELINE configuration
 TARGET = 0.1
+BOUND_DB_1E2 = 0.10  # stated bound at BLER 1e-2, equal iteration caps (headline, cfg3 R = 1/3)
+
+
+def _threads():
+    """CPU threads for the sum-product oracle: the cgroup quota, not the 256 CPUs a GPU box shows."""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 # name, bg, Z, K' (payload + CRC bits), E (transmitted bits, rv0), active layers, iteration cap, Es/N0 grid, blocks
 CASES = [
@@ -67,7 +85,7 @@ def test_db_gap_to_flooding_sum_product(pkg, orc, case):
         llr[:, 2 * Z + E + (K - Kp):] = 0           # beyond the E transmitted non-filler bits (k0 = 0)
         llr[:, Kp:K] = np.inf                       # fillers (NRLDPCDecoder.m:264)
         hg, ig = codec.decode(llr.astype(np.float32), want_iters=True)
-        hb, ib = orc.decode_bp_flood(bg, Z, llr, iters, n_layers=nl)
+        hb, ib = orc.decode_bp_flood(bg, Z, llr, iters, n_layers=nl, nthreads=_threads())
         b_gpu.append(float((hg[:, :Kp] != info[:, :Kp]).any(1).mean()))
         b_bp.append(float((hb[:, :Kp] != info[:, :Kp]).any(1).mean()))
         it_gpu.append(float(ig.mean())); it_bp.append(float(ib.mean()))
@@ -94,3 +112,63 @@ def test_db_gap_to_flooding_sum_product(pkg, orc, case):
     assert x_gpu is not None and x_bp is not None, "grid does not bracket BLER 0.1: %s %s" % (b_gpu, b_bp)
     assert x_gpu - x_bp <= BOUND_DB, rec
     assert all(b_gpu[i] >= b_gpu[i + 1] - 0.02 for i in range(len(snrs) - 1))  # monotone up to sampling noise
+
+
+# name (as in CASES), bg, Z, K', E, layers, iteration cap, grid at equal caps, grid of the 50-sweep sum-product reference, blocks
+CASES_1E2 = [
+    ("cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25, [-1.40, -1.35, -1.30, -1.25, -1.20], [-1.70, -1.65, -1.60, -1.55, -1.50], 4096),
+    ("cfg3 BG2 Z=384 R=1/3 25it", 2, 384, 3840, 11472, 22, 25, [-1.30, -1.20, -1.10, -1.00, -0.90], [-1.60, -1.50, -1.40, -1.30, -1.20], 4096),
+]
+
+
+@pytest.mark.parametrize("case", CASES_1E2, ids=[c[0] for c in CASES_1E2])
+def test_db_gap_at_bler_1e2(pkg, orc, case):
+    name, bg, Z, Kp, E, nl, iters, snrs, snrs50, nblk = case
+    rows, cols, kb = BG_DIMS[bg]
+    K = kb * Z
+    rng = np.random.default_rng(zlib.crc32((name + " 1e-2").encode()))
+    codec = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=True, llr_dtype=np.float32)
+    info = rng.integers(0, 2, (nblk, K), dtype=np.uint8)
+    info[:, Kp:] = 0
+    cw = codec.encode(info)
+    noise = rng.standard_normal(cw.shape).astype(np.float32)
+    nth = _threads()
+
+    def llr_at(snr):
+        mu = 2 * 10 ** (snr / 10)
+        llr = ((1 - 2.0 * cw) * mu + np.sqrt(2 * mu) * noise).astype(np.float64)
+        llr[:, : 2 * Z] = 0
+        llr[:, 2 * Z + E + (K - Kp):] = 0
+        llr[:, Kp:K] = np.inf
+        return llr
+    b_gpu, b_bp, b_bp50 = [], [], []
+    for snr in snrs:
+        llr = llr_at(snr)
+        hg = codec.decode(llr.astype(np.float32))
+        hb, _ = orc.decode_bp_flood(bg, Z, llr, iters, n_layers=nl, nthreads=nth)
+        b_gpu.append(float((hg[:, :Kp] != info[:, :Kp]).any(1).mean()))
+        b_bp.append(float((hb[:, :Kp] != info[:, :Kp]).any(1).mean()))
+    for snr in snrs50:  # the reference's default iteration count (NRLDPCDecoder.m:41)
+        hb, _ = orc.decode_bp_flood(bg, Z, llr_at(snr), 50, n_layers=nl, nthreads=nth)
+        b_bp50.append(float((hb[:, :Kp] != info[:, :Kp]).any(1).mean()))
+    codec.close()
+    x_gpu, x_bp, x_bp50 = crossing(snrs, b_gpu, nblk, 1e-2), crossing(snrs, b_bp, nblk, 1e-2), crossing(snrs50, b_bp50, nblk, 1e-2)
+    extra = {"blocks_at_bler_0.01": nblk, "EsN0_dB_at_bler_0.01_grid": snrs, "bler_gpu_fine": b_gpu, "bler_sum_product_fine": b_bp,
+             "EsN0_at_bler_0.01_gpu": x_gpu, "EsN0_at_bler_0.01_sum_product": x_bp,
+             "gap_dB_at_bler_0.01": None if x_gpu is None or x_bp is None else x_gpu - x_bp, "bound_dB_at_bler_0.01": BOUND_DB_1E2,
+             "EsN0_dB_grid_50_sweeps": snrs50, "bler_sum_product_50_sweeps": b_bp50, "EsN0_at_bler_0.01_sum_product_50_sweeps": x_bp50,
+             "gap_dB_vs_50_sum_product_sweeps_at_bler_0.01": None if x_gpu is None or x_bp50 is None else x_gpu - x_bp50,
+             "note_50_sweeps": "recorded, not bounded: %d layered min-sum iterations against the reference's default of 50 "
+                               "flooding sum-product sweeps (NRLDPCDecoder.m:41)" % iters}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        p = os.path.join(out, "bler_gap.json")
+        allr = json.load(open(p)) if os.path.exists(p) else {}
+        allr.setdefault(name, {"case": name}).update(extra)
+        json.dump(allr, open(p, "w"), indent=1)
+    except OSError:
+        pass
+    print(extra)
+    assert x_gpu is not None and x_bp is not None, "grid does not bracket BLER 1e-2: %s %s" % (b_gpu, b_bp)
+    assert x_gpu - x_bp <= BOUND_DB_1E2, extra

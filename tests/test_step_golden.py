@@ -67,8 +67,11 @@ def test_device_chain_state_reproduces_fixture(pkg, scenario):
         a_hat, ok, _ = chain.step(torch.from_numpy(llr.astype(np.float32)).cuda())
         res.append((a_hat.cpu().numpy(), ok.cpu().numpy(), chain.cb_pass.cpu().numpy()))
     check(res, want, a, scenario)
-    with pytest.raises(pkg.NRLDPCError):        # state pending: a different batch size needs an explicit reset()
+    if scenario == "noharq":                    # I_HARQ == 0: nothing is pending, a new batch size starts a new set
         chain.step(torch.zeros((2, p.G), dtype=torch.float32, device="cuda"))
+    else:                                       # HARQ state pending: a different batch size needs an explicit reset()
+        with pytest.raises(pkg.NRLDPCError):
+            chain.step(torch.zeros((2, p.G), dtype=torch.float32, device="cuda"))
     chain.reset()
     a_hat, ok, _ = chain.step(torch.from_numpy(steps[0][3][:2].astype(np.float32)).cuda() if steps[0][2] == p.G
                               else torch.zeros((2, p.G), dtype=torch.float32, device="cuda"))

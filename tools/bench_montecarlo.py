@@ -13,14 +13,12 @@ DC = importlib.import_module("ldpc-3gpp-matlab_amd.device_chain")
 def run(name, batch, esn0, reps=12, **props):
     p = pkg.NRLDPC(**props); p.validate()
     tx = DC.DeviceEncodeChain(p); rx = DC.DeviceDecodeChain(p, iterations=25, I_HARQ=0)
-    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
-    chan = [1234, 0]
-    H.simulate_point_device(tx, rx, p.Q_m, esn0, (0,), batch, gen, chan)
+    H.simulate_point_device([(tx, rx)], p.Q_m, esn0, (0,), batch, 1234, 0)
     torch.cuda.synchronize()
     ts, errs = [], 0
-    for _ in range(reps):
+    for i in range(reps):
         t0 = time.perf_counter()
-        ok = H.simulate_point_device(tx, rx, p.Q_m, esn0, (0,), batch, gen, chan)
+        ok = H.simulate_point_device([(tx, rx)], p.Q_m, esn0, (0,), batch, 1234, (i + 1) * batch)
         ts.append(time.perf_counter() - t0); errs += int((~ok).sum())
     tx.close(); rx.close()
     ts.sort(); med = ts[len(ts) // 2]

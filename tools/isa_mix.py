@@ -9,7 +9,10 @@ against the measured kernel time (bench.py / profiles/r02_bench_kernel_stats.csv
 (profiles/r02_bench_pmc_summary.json).  The per-wave mirror-coherence dispatch inside the loop holds only LDS writes,
 scalar compares and branches, so the static VALU count of the loop is the count every wave executes.
 
-    python tools/isa_mix.py [--bg 1 --z 384] [--kernel-ms 4.03] > profiles/r02_headline_isa_mix.txt
+--form row: the one-thread-per-row kernel (one loop).  --form split: the two-threads-per-row kernel
+(nrldpc_decode_z64s.h): one loop per half; a row's work per iteration is the SUM of both loops.
+
+    python tools/isa_mix.py [--bg 1 --z 384] [--form split] [--kernel-ms 3.3] [--json profiles/r03_headline_isa_mix.json] > profiles/r03_headline_isa_mix.txt
 """
 import argparse, collections, os, re, subprocess, sys, tempfile
 
@@ -21,9 +24,12 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 def rates():
     """mnemonic -> issue interval in ns per wave64 instruction per SIMD (the table quotes cycles at a nominal 2.4 GHz)."""
     tab = {}
-    for line in open(os.path.join(ROOT, "profiles", "r02_ubench_valu_rates.txt")):
+    path = os.path.join(ROOT, "profiles", "r03_ubench_valu_rates.txt")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r02_ubench_valu_rates.txt")
+    for line in open(path):
         m = re.match(r"(v_[a-z0-9_]+)[^>]*-> ([0-9.]+) cycles/inst", line)
-        if m and m.group(1) not in tab and "cndmask" not in m.group(1):  # (the v_cndmask lines measure a vcc dependency chain)
+        if m and m.group(1) not in tab and not (m.group(1).startswith("v_cndmask") and float(m.group(2)) > 10):  # (r02's v_cndmask lines measured a vcc dependency chain)
             tab[m.group(1)] = float(m.group(2)) / 2.4
     return tab
 
@@ -35,7 +41,7 @@ def price(op, tab):
     if base in tab:
         return tab[base], "measured"
     if base == "v_cndmask_b32":
-        return tab["v_mov_b32"], "as v_mov_b32"     # full rate; its ubench line is a dependency chain, not an issue rate
+        return tab["v_mov_b32"], "as v_mov_b32"     # no independent-chain measurement in the table: priced as v_mov_b32
     if base in ("v_max_f32", "v_min_f32"):
         return tab["v_min_f32"], "measured"
     return tab["v_add_f32"], "assumed full rate"
@@ -49,6 +55,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=25)
     ap.add_argument("--launch-invariant-ms", type=float, default=0.06)
+    ap.add_argument("--form", default="split", choices=("row", "split"))
+    ap.add_argument("--json", default=None, help="also write the totals (with nrldpc_kernel_id) for bench.py")
     a = ap.parse_args()
     tab = rates()
     with tempfile.TemporaryDirectory() as td:
@@ -57,38 +65,45 @@ def main():
                                "-I" + CSRC, "-DNRLDPC_Z64_BG=%d" % a.bg, "-DNRLDPC_Z64_Z=%d" % a.z, "--cuda-device-only",
                                "--no-gpu-bundle-output", "-c", os.path.join(CSRC, "nrldpc_decode_z64_inst.hip"), "-o", co])
         dis = subprocess.check_output([OBJDUMP, "-d", co], text=True)
-    # the fixed-iteration build: template arguments <BG, Z, NCWG, FULL=1, PLAIN=1, ETP=0, NL>
+    # the fixed-iteration build: row form <BG, Z, NCWG, FULL=1, PLAIN=1, ETP=0, NL>; split form <BG, Z, ETP=0, NL>
+    pat = (r"nrldpc_decode_z64_kernelILi%dELi%dELi\d+ELb1ELb1ELb0E" if a.form == "row" else r"nrldpc_decode_z64s_kernelILi%dELi%dELb0E") % (a.bg, a.z)
     cur, body = None, []
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if m:
             cur = m.group(1)
             continue
-        if cur and re.search(r"nrldpc_decode_z64_kernelILi%dELi%dELi\d+ELb1ELb1ELb0E" % (a.bg, a.z), cur):
+        if cur and re.search(pat, cur):
             m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*//\s*([0-9A-F]+):", line)
             if m:
                 body.append((int(m.group(3), 16), m.group(1), m.group(2)))
     assert body, "kernel not found"
-    addr = [b[0] for b in body]
-    best = None  # the backward branch with the longest span closes the iteration loop
+    spans = []  # backward branches: the longest closes the iteration loop (split form: one loop per half)
     for ad, op, args in body:
         if op.startswith("s_cbranch") or op == "s_branch":
             off = int(args.split()[0])
             if off >= 32768:
-                tgt = ad + 4 + (off - 65536) * 4
-                if best is None or ad - tgt > best[1] - best[0]:
-                    best = (tgt, ad)
-    lo, hi = best
-    loop = [b for b in body if lo <= b[0] <= hi]
+                spans.append((ad + 4 + (off - 65536) * 4, ad))
+    spans.sort(key=lambda t: t[0] - t[1])
+    keep = [spans[0]]
+    if a.form == "split":
+        for sp in spans[1:]:
+            if sp[1] - sp[0] >= 0.3 * (spans[0][1] - spans[0][0]) and all(sp[1] < k[0] or sp[0] > k[1] for k in keep):
+                keep.append(sp)
+        assert len(keep) == 2, "expected one iteration loop per half, found %d" % len(keep)
+    loop = [b for b in body if any(lo <= b[0] <= hi for lo, hi in keep)]
+    lo, hi = min(k[0] for k in keep), max(k[1] for k in keep)
+    loop_bytes = sum(k[1] - k[0] for k in keep)
     cnt = collections.Counter(op for _, op, _ in loop)
     cls = collections.Counter()
     for op, n in cnt.items():
         c = "VALU" if op.startswith("v_") else "LDS" if op.startswith("ds_") else "barrier" if op == "s_barrier" else \
             "waitcnt/nop" if op in ("s_waitcnt", "s_nop") else "SALU/branch" if op.startswith("s_") else "VMEM"
         cls[c] += n
-    print("# tools/isa_mix.py: iteration loop of nrldpc_decode_z64_kernel<BG=%d, Z=%d, FULL, PLAIN> (device-only compile of the tree's sources)" % (a.bg, a.z))
-    print("# loop = code between the longest backward branch and its target: %d instructions, %.1f KB" % (len(loop), (hi - lo) / 1024.0))
-    print("instruction classes per iteration and wave:", dict(cls))
+    print("# tools/isa_mix.py: iteration loop%s of the %s kernel, BG=%d Z=%d, fixed iteration count (device-only compile of the tree's sources)" % (
+        "s (one per half, summed)" if a.form == "split" else "", "two-threads-per-row (split)" if a.form == "split" else "one-thread-per-row", a.bg, a.z))
+    print("# loop = code between a long backward branch and its target: %d instructions, %.1f KB in total" % (len(loop), loop_bytes / 1024.0))
+    print("instruction classes per iteration, summed over the waves that serve one block of 64 rows:", dict(cls))
     edges = {1: 316, 2: 197}[a.bg]
     rows = {1: 46, 2: 42}[a.bg]
     print("VALU per edge and iteration: %.2f (%d edges, %d check rows per thread)" % (cls["VALU"] / edges, edges, rows))
@@ -112,13 +127,21 @@ def main():
     rounds = a.batch / 2.0 / cus
     valu_ms = total * wps * a.iters * rounds * 1e-6
     print()
-    print("VALU-bound time of the timed launch: %.1f ns x %.1f waves per SIMD x %d iterations x %.1f workgroup rounds = %.3f ms" % (
+    print("VALU-bound time of the timed launch: %.1f ns x %.1f row blocks per SIMD (2 codewords per CU) x %d iterations x %.1f rounds = %.3f ms" % (
         total, wps, a.iters, rounds, valu_ms))
     print("measured kernel time %.3f ms (of which %.2f ms launch-invariant: workgroup start, LLR ingest, write-back)" % (a.kernel_ms, a.launch_invariant_ms))
     print("cycle-weighted VALU roofline fraction: %.3f of the kernel, %.3f of its iteration part" % (
         valu_ms / a.kernel_ms, valu_ms / (a.kernel_ms - a.launch_invariant_ms)))
-    print("(compare SQ_ACTIVE_INST_VALU / busy cycles = valu_pipe_busy in profiles/r02_bench_pmc_summary.json; the 2-cycle-per-op")
-    print(" VALU-issue fraction of the bench line prices every op at the full rate and reads 0.40 for the same launch)")
+    print("(compare SQ_ACTIVE_INST_VALU / busy cycles in profiles/r03_bench_pmc_summary.json; the 2-cycle-per-op VALU-issue fraction")
+    print(" of the bench line prices every op at the full rate)")
+    if a.json:
+        import importlib, json
+        sys.path.insert(0, ROOT)
+        kid = importlib.import_module("ldpc-3gpp-matlab_amd.build").kernel_id()
+        json.dump({"nrldpc_kernel_id": kid, "bg": a.bg, "Z": a.z, "form": a.form, "valu_instructions_per_iteration_all_waves_of_a_row": cls["VALU"],
+                   "valu_ns_per_iteration_all_waves_of_a_row": total, "lds_instructions": cls["LDS"], "barriers": cls["barrier"],
+                   "loop_bytes": loop_bytes, "source": "tools/isa_mix.py (static disassembly x measured issue intervals)"},
+                  open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":

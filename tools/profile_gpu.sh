@@ -8,7 +8,14 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-e2e $*"
+BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --cpu-sample 0 --no-e2e --no-early-term $*"
+# which build the counters belong to (bench.py drops a summary whose kernel id is not the loaded library's)
+python - > $OUT/ids.json <<PY
+import importlib, json, sys
+sys.path.insert(0, "$ROOT")
+L = importlib.import_module("ldpc-3gpp-matlab_amd").load()
+print(json.dumps({"nrldpc_build_id": L.nrldpc_build_id().decode(), "nrldpc_kernel_id": L.nrldpc_kernel_id().decode()}))
+PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 pmc() { # name, counters...
   local name=$1; shift

@@ -6,7 +6,9 @@
 Writes
   profiles/<tag>_bench_kernel_stats.csv    the --kernel-trace --stats per-kernel table, verbatim
   profiles/<tag>_bench_pmc_summary.json    mean per launch of every PMC counter, dominant kernel only
-  profiles/traffic_bytes_per_launch.json   HBM bytes per launch (bench.py reads this for roofline.traffic)
+  profiles/<tag>_traffic_bytes_per_launch.json   HBM bytes per launch (bench.py reads this for roofline.traffic)
+Every summary carries nrldpc_build_id / nrldpc_kernel_id of the library that was profiled (gpurun_out/prof_<tag>/ids.json).
+The kernel-trace average excludes the first (warm-up) launch of the dominant kernel.
 
 HBM correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in KiB; on
 gfx950 FETCH_SIZE counts each 128-byte request as 64 bytes, so fetched bytes = 2 * FETCH_SIZE * 1024.
@@ -53,7 +55,25 @@ def main():
         if os.path.exists(p):
             summary.update(per_launch(p, kernel))
     summary["_kernel"] = kernel
-    summary["_avg_ns_kernel_trace"] = float(rows[0]["AverageNs"])
+    summary["_avg_ns_kernel_trace_all_launches"] = float(rows[0]["AverageNs"])
+    ids = {}
+    try:
+        ids = json.load(open(os.path.join(src, "ids.json")))
+    except (OSError, ValueError):
+        pass
+    summary["_nrldpc_build_id"] = ids.get("nrldpc_build_id")
+    summary["_nrldpc_kernel_id"] = ids.get("nrldpc_kernel_id")
+    # per-launch durations of the dominant kernel from the kernel trace, first (warm-up) launch excluded
+    trace = os.path.join(src, "stats", "stats_kernel_trace.csv")
+    if os.path.exists(trace):
+        with open(trace, newline="") as f:
+            d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(f)
+                 if r["Kernel_Name"] == kernel]
+        d.sort()
+        dur = [x[1] for x in d][1:] if len(d) > 1 else [x[1] for x in d]
+        summary["_kernel_trace"] = {"launches": len(d), "avg_ns_without_first_launch": sum(dur) / len(dur), "min_ns": min(dur),
+                                    "max_ns": max(dur), "first_launch_ns": d[0][1]}
+        print("kernel trace without the warm-up launch: avg %.0f ns over %d launches" % (sum(dur) / len(dur), len(dur)))
     with open(os.path.join(dst, tag + "_bench_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
 
@@ -72,7 +92,8 @@ def main():
             "hbm_bytes_per_launch": hbm,
             "hbm_bytes_per_codeword": hbm / batch,
         }
-        with open(os.path.join(dst, "traffic_bytes_per_launch.json"), "w") as f:
+        out["nrldpc_build_id"], out["nrldpc_kernel_id"] = ids.get("nrldpc_build_id"), ids.get("nrldpc_kernel_id")
+        with open(os.path.join(dst, tag + "_traffic_bytes_per_launch.json"), "w") as f:
             json.dump(out, f, indent=1)
         print("HBM bytes per launch:", hbm, "per codeword:", hbm / batch)
 
