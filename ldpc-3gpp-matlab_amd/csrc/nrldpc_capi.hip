@@ -325,6 +325,7 @@ struct nrldpc_codec {
     int p0_shift = 0, step_row[3] = {0, 0, 0}, step_col[3] = {0, 0, 0}, step_shift[3] = {0, 0, 0};
     int step_nk[3] = {0, 0, 0}, step_kcol[3][3] = {}, step_kshift[3][3] = {}; // already-known core blocks in that row
     // host-entry staging
+    DevBuf<float> s_rr; // nrldpc_decode_tb_dev's staging buffer (lifting sizes without the fused prologue)
     DevBuf<char> s_llr;
     DevBuf<int8_t> s_q; // int8 chunks of the pipelined host path, one region per slot
     DevBuf<uint8_t> s_hard, s_bits;
@@ -581,7 +582,7 @@ void nrldpc_destroy(nrldpc_handle h) {
     DeviceScope scope(h->cfg.device_id);
     h->d_rot.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
-    h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
+    h->s_rr.release(); h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
     for (int i = 0; i < 3; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
@@ -1108,17 +1109,13 @@ static int check_tb_params(const nrldpc_tb_params* p) {
     return NRLDPC_OK;
 }
 
-int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
-                            void* d_cw_llr, int32_t out_dtype, void* stream) {
-    int rc = check_tb_params(p);
-    if (rc) return rc;
-    if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
-    if (n_tb == 0) return NRLDPC_OK;
+static int make_rm_args(const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq, void* d_cw_llr,
+                        int32_t out_dtype, nrldpc::RmArgs* out) {
     // G == 0 is a legal draw of the reference's own sweep (testbench.m:35 with a small A): nothing was transmitted, the
     // decoder input is all zeros / fillers, and an empty g_tilde has no address
-    if ((!d_g_tilde && p->G > 0) || !d_cw_llr) return fail(NRLDPC_ERR_ARG, "null pointer");
-    if (out_dtype != NRLDPC_LLR_F32 && out_dtype != NRLDPC_LLR_F16) return fail(NRLDPC_ERR_ARG, "out_dtype must be f32 or f16");
-    nrldpc::RmArgs a;
+    if (!d_g_tilde && p->G > 0) return fail(NRLDPC_ERR_ARG, "null pointer");
+    nrldpc::RmArgs& a = *out;
+    memset(&a, 0, sizeof a);
     a.g = d_g_tilde; a.harq = d_harq; a.out = d_cw_llr; a.out_f16 = out_dtype == NRLDPC_LLR_F16;
     a.n_tb = n_tb; a.C = p->C; a.G = p->G; a.Z = p->Z; a.K = p->K; a.Kp = p->K_prime; a.N = p->N; a.N_cb = p->N_cb;
     a.k0 = p->k_0; a.Qm = p->Q_m;
@@ -1128,9 +1125,72 @@ int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, i
         a.E[r] = p->E_r[r]; a.off[r] = off; off += p->E_r[r];
     }
     if (off != p->G) return fail(NRLDPC_ERR_ARG, "sum(E_r) must equal G");
+    return NRLDPC_OK;
+}
+
+int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
+                            void* d_cw_llr, int32_t out_dtype, void* stream) {
+    int rc = check_tb_params(p);
+    if (rc) return rc;
+    if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (n_tb == 0) return NRLDPC_OK;
+    if (!d_cw_llr) return fail(NRLDPC_ERR_ARG, "null pointer");
+    if (out_dtype != NRLDPC_LLR_F32 && out_dtype != NRLDPC_LLR_F16) return fail(NRLDPC_ERR_ARG, "out_dtype must be f32 or f16");
+    nrldpc::RmArgs a;
+    rc = make_rm_args(p, d_g_tilde, n_tb, d_harq, d_cw_llr, out_dtype, &a);
+    if (rc) return rc;
     hipError_t e = nrldpc::launch_rate_recover(a, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hipfail(e, "rate-recovery kernel launch");
     return NRLDPC_OK;
+}
+
+int nrldpc_decode_tb_dev(nrldpc_handle h, const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
+                         uint8_t* d_c_hat, int32_t* d_iters_out, void* stream) {
+    NRLDPC_API_BEGIN
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    int rc = check_tb_params(p);
+    if (rc) return rc;
+    if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
+    if (n_tb == 0) return NRLDPC_OK;
+    if (!d_c_hat) return fail(NRLDPC_ERR_ARG, "null pointer");
+    const nrldpc::Schedule& s = h->sched;
+    if (p->bg != s.g.bg || p->Z != s.Z || p->N + 2 * p->Z != s.g.ncols * s.Z || p->K != s.g.kb * s.Z)
+        return fail(NRLDPC_ERR_ARG, "transport-block parameters do not belong to this codec's (BG, Z)");
+    if ((long long)n_tb * p->C > 0x7fffffffLL) return fail(NRLDPC_ERR_ARG, "too many code blocks");
+    const int batch = n_tb * p->C;
+    DEVICE_SCOPE(h);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static const bool no_fuse = getenv("NRLDPC_NO_FUSED_RR") != nullptr; // A/B: always the two-launch path
+    if (nrldpc::decode_supports_rr(s.g.bg, s.Z) && !no_fuse) {
+        // ONE launch: the decoder's prologue gathers its input from g_tilde (and updates the HARQ buffer) itself.  The
+        // argument block travels through the ring of pinned / device table slots (as nrldpc_decode_multi_dev's tables).
+        nrldpc::RmArgs ra;
+        rc = make_rm_args(p, d_g_tilde, n_tb, d_harq, nullptr, NRLDPC_LLR_F32, &ra);
+        if (rc) return rc;
+        nrldpc_codec::MultiSlot& m = h->multi[h->multi_next];
+        h->multi_next = (h->multi_next + 1) % nrldpc_codec::kMultiSlots;
+        if (!m.done) HIP_TRY(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
+        if (m.used) HIP_TRY(hipEventSynchronize(m.done));
+        HIP_TRY(m.pin.reserve(sizeof ra));
+        HIP_TRY(m.dev.reserve(sizeof ra));
+        memcpy(m.pin.p, &ra, sizeof ra);
+        HIP_TRY(hipMemcpyAsync(m.dev.p, m.pin.p, sizeof ra, hipMemcpyHostToDevice, st));
+        nrldpc::DecArgs a = make_dec_args(h, nullptr, batch, d_c_hat, d_iters_out, nullptr, NRLDPC_K_RR);
+        a.rr = reinterpret_cast<const nrldpc::RmArgs*>(m.dev.p);
+        begin_timing(h, st);
+        hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, st);
+        end_timing(h, st);
+        (void)hipEventRecord(m.done, st); // also on a failed launch: the copy above is in flight
+        m.used = true;
+        if (e != hipSuccess) return hipfail(e, "decode kernel launch (fused rate recovery)");
+        return NRLDPC_OK;
+    }
+    // lifting sizes served by the run-time-Z kernel: rate recovery into a float staging buffer of the handle, then the decode
+    HIP_TRY(h->s_rr.reserve((size_t)batch * s.g.ncols * s.Z));
+    rc = nrldpc_rate_recover_dev(p, d_g_tilde, n_tb, d_harq, h->s_rr.p, NRLDPC_LLR_F32, stream);
+    if (rc) return rc;
+    return decode_launch(h, h->s_rr.p, batch, d_c_hat, d_iters_out, nullptr, st, NRLDPC_K_F32);
+    NRLDPC_API_END
 }
 
 static int crc_check_common(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat, int32_t* d_ok,

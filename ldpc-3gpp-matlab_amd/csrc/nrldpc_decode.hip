@@ -327,6 +327,8 @@ bool has_z64_kernel(int bg, int Z) {
     return false;
 }
 
+bool decode_supports_rr(int bg, int Z) { return has_z64_kernel(bg, Z); } // every build of the compile-time-Z kernels
+
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
     const bool force_generic = force_generic_env();
 #define NRLDPC_Z64_CASE(b, z) if (!force_generic && bg == b && a.Z == z) return launch_decode_z64_##b##_##z(a, stream);

@@ -694,7 +694,27 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
                 f32_to_byte<i & 3>(st.xq[i >> 2], ingest(val(xe[i]), a.scale, false));
             });
         };
-        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        // llr_kind == NRLDPC_K_RR: no LLR array -- this prologue IS the rate recovery (rr_value: NRLDPCDecoder.m:143-242,
+        // 262-264 per position, straight from the demodulator's LLRs), one ring position per thread and column.  With a HARQ
+        // buffer every position of the code block is visited, also the columns a pruned layer count never reads: the
+        // buffer has to hold them for the retransmissions to come.
+        auto ingest_rr = [&]() {
+            const RrBlock rb = rr_block(a.rr, cw);
+            static_for<G::NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const float q = ingest(rr_value(rb, c * ZC + z), a.scale, true);
+                *reinterpret_cast<float*>(home + c * G::CS) = q;
+                if (w == 0) *reinterpret_cast<float*>(home + c * G::CS + ZC * 4) = q; // mirror of block 0
+            });
+            static_for<G::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float v = 0.0f;
+                if (rb.hb || (FULL && NL == G::ROWS) || i < next_used) v = rr_value(rb, (G::NC + i) * ZC + z);
+                f32_to_byte<i & 3>(st.xq[i >> 2], ingest(v, a.scale, false));
+            });
+        };
+        if (a.llr_kind == NRLDPC_K_RR) ingest_rr();
+        else if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
         else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
         if (app_row) {
             static_for<G::NEXT>([&](auto ic) {
@@ -749,13 +769,25 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             // far from convergence the pass costs ~19 LDS reads per thread instead of all 274.
             uint32_t bad = 0;
             bool stop = false; // wave-uniform
-            static_for<NL>([&](auto lc) {
-                constexpr int L = decltype(lc)::value;
-                if (!stop && (FULL || L < launder(a.n_layers))) {
-                    bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
-                    if constexpr (L < 4 || (L % 4) == 3) stop = __any((int)bad) != 0;
-                }
-            });
+            if constexpr (FULL) { // the active rows are a compile-time fact: cheapest rows first (Own::parity_order)
+                constexpr auto PO = Own<BG, NL, -1>::parity_order();
+                static_for<PO.n>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int L = PO.v[i];
+                    if (!stop) {
+                        bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                        if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n) stop = __any((int)bad) != 0;
+                    }
+                });
+            } else {
+                static_for<NL>([&](auto lc) {
+                    constexpr int L = decltype(lc)::value;
+                    if (!stop && L < launder(a.n_layers)) {
+                        bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                        if constexpr (L < 4 || (L % 4) == 3) stop = __any((int)bad) != 0;
+                    }
+                });
+            }
             if (bad) { flags[cwl] = 1; flags[G::NCWG] = 1; }
         }
         __syncthreads();
@@ -893,7 +925,9 @@ template <int BG, int ZC, int NL> constexpr bool z64_split_default() {
 #ifdef NRLDPC_Z64_SPLIT
     return NRLDPC_Z64_SPLIT != 0;
 #endif
-    if (NL != BGT<BG>::ROWS) return BG == 1 && ZC == 384 && NL <= 6; // the R = 8/9 shard of BASELINE configs[4]
+    // pruned layer counts: BG1 Z = 384 {5, 13, 24} -- with the parity-check stop +10 % / +21 % / +14 %, fixed-25 -3 % /
+    // +6 % / +4 % (profiles/r03_forms_nl.txt); the BG2 counts of BASELINE configs[2] lose 10-19 % and stay with the row form
+    if (NL != BGT<BG>::ROWS) return BG == 1 && ZC == 384;
     if (BG == 1)
         return ZC == 60 || ZC == 64 || ZC == 104 || ZC == 112 || ZC == 120 || ZC == 128 || ZC == 176 || ZC == 208 || ZC == 224 ||
                ZC == 240 || ZC == 256 || ZC == 288 || ZC == 384;

@@ -55,7 +55,9 @@ __device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ6
                                        const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
                                        float cap, uint32_t& esign_lo, uint32_t& esign_hi) {
     constexpr int NG = LayerGroups<BG, NL>::ngroups();
-    __syncthreads(); // ends interval GI-1: group GI-1's writes are visible
+    // ends interval GI-1: group GI-1's writes are visible.  With early termination the parity pass between two iterations
+    // ends with a barrier of its own (and the first iteration follows the prologue's), so interval 0 needs none.
+    if constexpr (!(ET && GI == 0)) __syncthreads();
     __builtin_amdgcn_s_setprio(NRLDPC_Z64S_PRIO); // the next barrier waits for this half
     cur.template loads<true>(lds, R);
     cur.template track<true, XF>(st, cap);
@@ -82,7 +84,7 @@ __device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& s
                                         uint32_t RA, uint32_t RB, int w, const DecArgs& a, float cap, uint32_t& esign_lo,
                                         uint32_t& esign_hi) {
     constexpr int NG = LayerGroups<BG, NL>::ngroups();
-    __syncthreads();
+    if constexpr (!(ET && GI == 0)) __syncthreads(); // see s_crit
     if constexpr (GI + 1 < NG) {
         GroupZ64<BG, ZC, GI + 1, NL, H> nxt;
         nxt.template loads<false>(lds, R); // columns group GI does not write
@@ -189,7 +191,27 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                 });
             }
         };
-        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        if (a.llr_kind == NRLDPC_K_RR) {
+            // no LLR array: this prologue IS the rate recovery (rr_value, nrldpc_device.h); the halves take alternate columns
+            const RrBlock rb = rr_block(a.rr, cw);
+            static_for<(G::NC + 1) / 2>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int c = 2 * k + half;
+                if (2 * k + 1 < G::NC || c < G::NC) {
+                    const float q = ingest(rr_value(rb, c * ZC + z), a.scale, true);
+                    char* home = lds + G::GUARD + 4 * z + c * G::CS;
+                    *reinterpret_cast<float*>(home) = q;
+                    if (w == 0) *reinterpret_cast<float*>(home + ZC * 4) = q;
+                }
+            });
+            // extension columns of rows a pruned layer count leaves out: never read, but a HARQ buffer has to hold them
+            if (rb.hb && half == 0) {
+                static_for<G::ROWS - NL>([&](auto ic) {
+                    constexpr int L = NL + decltype(ic)::value;
+                    (void)rr_value(rb, (G::NC + L - 4) * ZC + z);
+                });
+            }
+        } else if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
         else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
     }
 
@@ -225,7 +247,16 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                 f32_to_byte<i & 3>(st.xq[i >> 2], ingest(v, a.scale, false));
             });
         };
-        if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});
+        if (a.llr_kind == NRLDPC_K_RR) {
+            const RrBlock rb = rr_block(a.rr, cw);
+            static_for<NL - 4>([&](auto ic) {
+                constexpr int L = 4 + decltype(ic)::value;
+                if constexpr (O::mine(L)) {
+                    constexpr int xi = O::ext_index(L);
+                    f32_to_byte<xi & 3>(st.xq[xi >> 2], ingest(rr_value(rb, (G::NC + L - 4) * ZC + z), a.scale, false));
+                }
+            });
+        } else if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});
         else load_ext(std::integral_constant<int, NRLDPC_K_F32>{});
         if constexpr (XF) {
             static_for<O::NEXT>([&](auto ic) {
@@ -261,13 +292,13 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                 __syncthreads();
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform
-                static_for<NL>([&](auto lc) {
-                    constexpr int L = decltype(lc)::value;
-                    if constexpr (O::mine(L)) {
-                        if (!stop) {
-                            bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
-                            if constexpr (L < 4 || (O::ext_index(L) % 4) == 3) stop = __any((int)bad) != 0;
-                        }
+                constexpr auto PO = O::parity_order(); // cheapest rows first
+                static_for<PO.n>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int L = PO.v[i];
+                    if (!stop) {
+                        bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                        if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n) stop = __any((int)bad) != 0;
                     }
                 });
                 if (bad) flags[0] = 1;

@@ -107,6 +107,23 @@ template <int BG, int NL, int H> struct Own {
         for (int l = 4; l < L; ++l) n += mine(l) ? 1 : 0;
         return n;
     }
+    // this thread's rows among the NL active ones, cheapest (fewest core edges) first: the order of the parity pass, which
+    // stops reading at the first violated check of its wave -- far from convergence almost any row fails, and a
+    // two-edge row costs 2 LDS reads where row 0 costs 19
+    struct Order { int v[BGT<BG>::ROWS]; int n; };
+    static constexpr Order parity_order() {
+        Order o{};
+        o.n = 0;
+        for (int l = 0; l < NL; ++l)
+            if (mine(l)) o.v[o.n++] = l;
+        for (int i = 1; i < o.n; ++i) {
+            const int x = o.v[i];
+            int j = i - 1;
+            while (j >= 0 && ncore(o.v[j]) > ncore(x)) { o.v[j + 1] = o.v[j]; --j; }
+            o.v[j + 1] = x;
+        }
+        return o;
+    }
     static constexpr int NCORE = H < 0 ? G::NCORE : core_base(NL);
     static constexpr int NEXT = H < 0 ? G::NEXT : ext_index(NL);
     static constexpr int NW = (NCORE + 3) / 4, NXW = (NEXT + 3) / 4;
@@ -188,6 +205,61 @@ __device__ __forceinline__ float ingest(float x, float scale, bool core) {
 __device__ __forceinline__ float scale_mag(const DecArgs& a, float m) {
     const float y = __builtin_fmaf(a.alpha, m, 8388608.0f - a.beta);
     return __builtin_amdgcn_fmed3f(y, 8388608.0f, 8388608.0f + 127.0f) - 8388608.0f;
+}
+
+// ---- rate recovery inside the decoder's prologue (llr_kind == NRLDPC_K_RR) ------------------------------------------------
+// One decoder-input value straight from the demodulator's LLRs g_tilde: code_block_concatenation + bit_interleaving +
+// bit_selection with soft combining of repetitions + the HARQ buffer + the core's input conventions
+// (NRLDPCDecoder.m:143-242, 262-264), the arithmetic of nrldpc_rate_recover_kernel (nrldpc_ratematch.hip) per position, in
+// the same fp32 summation order (repetitions in ascending k, then the buffer).  The arguments live in device memory and are
+// read with scalar loads (wave-uniform addresses).
+struct RrBlock {
+    const float* f; // g_tilde segment of this code block
+    float* hb;      // its HARQ buffer row or null
+    int lo_f, hi_f, F, P, nfk0, E, rows, Qm, N_cb, Z2;
+};
+typedef const RmArgs __attribute__((address_space(4))) * rr_ctab_t;
+__device__ __forceinline__ RrBlock rr_block(const RmArgs* rrp, int blk) {
+    rr_ctab_t a = reinterpret_cast<rr_ctab_t>(reinterpret_cast<uintptr_t>(rrp));
+    RrBlock b;
+    const int C = a->C, tb = blk / C, r = blk - tb * C;
+    b.Z2 = 2 * a->Z;
+    b.N_cb = a->N_cb; b.Qm = a->Qm;
+    b.lo_f = a->Kp - b.Z2 > 0 ? a->Kp - b.Z2 : 0;
+    b.hi_f = a->K - b.Z2;
+    const int f_hi = b.hi_f < b.N_cb ? b.hi_f : b.N_cb;
+    b.F = f_hi > b.lo_f ? f_hi - b.lo_f : 0;
+    b.P = b.N_cb - b.F;
+    int c0 = a->k0 - b.lo_f;
+    c0 = c0 < 0 ? 0 : (c0 > b.F ? b.F : c0);
+    b.nfk0 = a->k0 - c0;
+    b.E = a->E[r];
+    b.rows = b.E > 0 ? b.E / b.Qm : 1;
+    b.f = a->g + (size_t)tb * a->G + a->off[r];
+    b.hb = a->harq ? a->harq + (size_t)blk * b.N_cb : nullptr;
+    return b;
+}
+// n: index into the decoder's input (0 .. ncols*Z-1); the first 2Z positions are the punctured columns (:262)
+__device__ __forceinline__ float rr_value(const RrBlock& b, int n) {
+    const int p = n - b.Z2;
+    if (p < 0) return 0.0f;
+    if (p >= b.lo_f && p < b.hi_f) return __builtin_inff(); // filler (:224, :264)
+    if (p >= b.N_cb) return 0.0f;                            // beyond the (limited) circular buffer
+    int c = p - b.lo_f;
+    c = c < 0 ? 0 : (c > b.F ? b.F : c);
+    int q = p - c - b.nfk0; // index among the buffer's non-filler positions counted from k_0
+    q += q < 0 ? b.P : 0;
+    float val = 0.0f;
+    for (int k = q; k < b.E; k += b.P) { // soft combining of repetitions, ascending k (:229-231)
+        int i = 0;
+        for (int m = 1; m < b.Qm; ++m) i += (k >= m * b.rows); // k / rows
+        val += b.f[(k - i * b.rows) * b.Qm + i];               // e(i*rows + j) = f(i + j*Qm)  (:191-195)
+    }
+    if (b.hb) { // :236-239
+        val += b.hb[p];
+        b.hb[p] = val;
+    }
+    return val;
 }
 
 template <int BG> struct DecState {

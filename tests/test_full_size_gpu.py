@@ -216,6 +216,34 @@ def test_pool_of_logical_shards_equals_one_launch(pkg, orc):
         pkg.CodecPool(bg, Z, [0, 99])                         # a device that does not exist: the whole pool fails
 
 
+def test_pool_decode_dev_shards_device_resident_batches(pkg, orc):
+    """nrldpc_pool_decode_dev: per-shard DEVICE pointers -- data that is already on the GPUs goes
+    through the pool without touching the host; one launching thread and stream per shard.  Three logical shards on this
+    box's GPU with unequal slices (one empty) against one plain decode; unmeasured on more than one GPU."""
+    import torch
+    rng = np.random.default_rng(81)
+    bg, Z, B = 2, 384, 1200
+    c = pkg.Codec(bg, Z, max_iter=20, early_term=True, llr_dtype=np.float16)
+    info = rng.integers(0, 2, (B, c.K), dtype=np.uint8)
+    llr = awgn_llr(rng, c.encode(info), -2.5, np.float16, Z)
+    ref_h, ref_i = c.decode(llr, want_iters=True)
+    c.close()
+    pool = pkg.CodecPool(bg, Z, [0, 0, 0, 0], max_iter=20, early_term=True, llr_dtype=np.float16)
+    cuts = [0, 500, 500, 1100, 1200]                          # shard 1 has nothing to do
+    d_llr = [torch.from_numpy(llr[cuts[i]:cuts[i + 1]]).cuda() for i in range(4)]
+    d_hard = [torch.full((cuts[i + 1] - cuts[i], c.K), 7, dtype=torch.uint8, device="cuda") for i in range(4)]
+    d_it = [torch.zeros(cuts[i + 1] - cuts[i], dtype=torch.int32, device="cuda") for i in range(4)]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        pool.decode_dev([t.data_ptr() for t in d_llr], [t.shape[0] for t in d_llr], [t.data_ptr() for t in d_hard],
+                        [t.data_ptr() for t in d_it])
+        got_h = torch.cat(d_hard).cpu().numpy()
+        got_i = torch.cat(d_it).cpu().numpy()
+        assert (got_h == ref_h).all() and (got_i == ref_i).all()
+        assert pool.last_split() == [500, 0, 600, 100]
+    pool.close()
+
+
 def test_bench_two_ranks_sharing_one_gpu():
     """bench.py launched the way the driver launches the scaling run (torch.distributed.run, one rank per 'GPU'), with
     both ranks on this box's single GPU and gloo for the barrier / max-over-ranks (RCCL refuses two ranks on one

@@ -120,7 +120,7 @@ def test_result_file_does_not_depend_on_the_number_of_shards(pkg, tmp_path):
     for kw in (dict(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=[0], iterations=8, target_block_errors=25,
                     target_BLER=2e-2, EsN0_start=-1.0, EsN0_delta=0.25, seed=3, batch=480),
                dict(A=1000, R=0.8, BG=1, Modulation="16QAM", rv_id_sequence=[0, 2, 3], iterations=10, target_block_errors=10,
-                    target_BLER=5e-2, EsN0_start=7.0, EsN0_delta=0.5, seed=9, batch=200)):
+                    target_BLER=5e-2, EsN0_start=-2.0, EsN0_delta=0.5, seed=9, batch=200, max_points=30)):
         files = []
         for shards in (1, 2, 4, 8):
             d = tmp_path / ("s%d_%d" % (shards, kw["A"]))
