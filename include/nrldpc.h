@@ -174,6 +174,7 @@ int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, i
  * its llr_dtype does not matter here.  Asynchronous on `stream`. */
 int nrldpc_decode_tb_dev(nrldpc_handle h, const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
                          uint8_t* d_c_hat, int32_t* d_iters_out, void* stream);
+int nrldpc_decode_tb_is_fused(nrldpc_handle h); /* 1: nrldpc_decode_tb_dev is one launch for this handle's (BG, Z); 0: two */
 
 /* CRC stages: replaces code_block_segmentation + crc_calculation of the decoder (NRLDPCDecoder.m:271-340).
  * d_c_hat: [n_tb*C][K] hard bits from nrldpc_decode_dev.  d_b_hat: [n_tb][B] bytes (a_hat = first A of a row).

@@ -1144,6 +1144,12 @@ int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, i
     return NRLDPC_OK;
 }
 
+int nrldpc_decode_tb_is_fused(nrldpc_handle h) {
+    if (!h) return 0;
+    static const bool no_fuse = getenv("NRLDPC_NO_FUSED_RR") != nullptr;
+    return (nrldpc::decode_supports_rr(h->sched.g.bg, h->sched.Z) && !no_fuse) ? 1 : 0;
+}
+
 int nrldpc_decode_tb_dev(nrldpc_handle h, const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
                          uint8_t* d_c_hat, int32_t* d_iters_out, void* stream) {
     NRLDPC_API_BEGIN
@@ -1160,8 +1166,7 @@ int nrldpc_decode_tb_dev(nrldpc_handle h, const nrldpc_tb_params* p, const float
     const int batch = n_tb * p->C;
     DEVICE_SCOPE(h);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const bool no_fuse = getenv("NRLDPC_NO_FUSED_RR") != nullptr; // A/B: always the two-launch path
-    if (nrldpc::decode_supports_rr(s.g.bg, s.Z) && !no_fuse) {
+    if (nrldpc_decode_tb_is_fused(h)) { // NRLDPC_NO_FUSED_RR in the environment: always the two-launch path (A/B)
         // ONE launch: the decoder's prologue gathers its input from g_tilde (and updates the HARQ buffer) itself.  The
         // argument block travels through the ring of pinned / device table slots (as nrldpc_decode_multi_dev's tables).
         nrldpc::RmArgs ra;

@@ -37,7 +37,10 @@ __device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zb, 
     constexpr bool HAS_EXT = (L >= 4);
     constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
     constexpr int ce0 = G::core_base(L);
-    const uint32_t zsb = (uint32_t)a.Z * (uint32_t)a.sbw;
+    // ring size in bytes as a VECTOR register value: any VALU op with a scalar operand issues at 4 cycles on gfx950, so
+    // the wrap's subtraction runs at the full rate this way (10 instead of 12 cycles of address arithmetic per edge)
+    uint32_t zsb = (uint32_t)a.Z * (uint32_t)a.sbw;
+    asm volatile("" : "+v"(zsb));
 
     float t[ncore];
     uint32_t ad[ncore];
@@ -69,16 +72,17 @@ __device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zb, 
         S ^= fbits(lam);
     }
     // magnitudes carrying the row's sign parity; the edge's own sign is xor-ed in per edge
-    const uint32_t Sm = S & 0x80000000u;
-    const float M1 = __uint_as_float(fbits(scale_mag(a, m1)) | Sm);
-    const float M2 = __uint_as_float(fbits(scale_mag(a, m2)) | Sm);
+    // M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
+    const float M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag(a, m1)), S, 0x80000000u, 0xF8));
+    const float M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag(a, m2)), S, 0x80000000u, 0xF8));
     static_for<ncore>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);
         constexpr int ce = ce0 + j;
         const float tj = t[j];
         const float mag = (fabsf(tj) == m1) ? M2 : M1;
-        const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
+        // mag ^ (t & signbit) in one v_bitop3_b32 (0x78 = a ^ (b & c))
+        const float r = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(mag), fbits(tj), 0x80000000u, 0x78));
         f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
         *reinterpret_cast<float*>(lds + ad[j] + 4 * c) = tj + r;
     });

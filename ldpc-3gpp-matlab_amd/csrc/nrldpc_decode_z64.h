@@ -700,16 +700,17 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         // buffer has to hold them for the retransmissions to come.
         auto ingest_rr = [&]() {
             const RrBlock rb = rr_block(a.rr, cw);
-            static_for<G::NC>([&](auto cc) {
+            rr_gather<G::NC>(rb, [&](auto cc) { return decltype(cc)::value * ZC + z; }, [&](auto cc, float v) {
                 constexpr int c = decltype(cc)::value;
-                const float q = ingest(rr_value(rb, c * ZC + z), a.scale, true);
+                const float q = ingest(v, a.scale, true);
                 *reinterpret_cast<float*>(home + c * G::CS) = q;
                 if (w == 0) *reinterpret_cast<float*>(home + c * G::CS + ZC * 4) = q; // mirror of block 0
             });
-            static_for<G::NEXT>([&](auto ic) {
+            rr_gather<G::NEXT>(rb, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                float v = 0.0f;
-                if (rb.hb || (FULL && NL == G::ROWS) || i < next_used) v = rr_value(rb, (G::NC + i) * ZC + z);
+                return (rb.hb || (FULL && NL == G::ROWS) || i < next_used) ? (G::NC + i) * ZC + z : -1;
+            }, [&](auto ic, float v) {
+                constexpr int i = decltype(ic)::value;
                 f32_to_byte<i & 3>(st.xq[i >> 2], ingest(v, a.scale, false));
             });
         };

@@ -262,6 +262,68 @@ __device__ __forceinline__ float rr_value(const RrBlock& b, int n) {
     return val;
 }
 
+// The same for N positions of one thread at once, arranged so that the prologue does not become a chain of dependent memory
+// round trips: without repetition (E_r <= non-filler positions of the buffer: a position takes one e(k) or none) all
+// index arithmetic comes first, then all loads are issued back to back, then the HARQ buffer's, then the values are
+// handed over.  pos(i) = decoder-input index of item i (negative: skip the item), put(i, value).  With repetition the
+// per-position walk of rr_value is used (rare: code rates below the mother code's).
+template <int N, class PosF, class PutF>
+__device__ __forceinline__ void rr_gather_n(const RrBlock& b, PosF&& pos, PutF&& put);
+template <int N, class PosF, class PutF>
+__device__ __forceinline__ void rr_gather(const RrBlock& b, PosF&& pos, PutF&& put) {
+    if constexpr (N > 0) rr_gather_n<N>(b, pos, put);
+}
+template <int N, class PosF, class PutF>
+__device__ __forceinline__ void rr_gather_n(const RrBlock& b, PosF&& pos, PutF&& put) {
+    if (b.E > b.P) { // wave-uniform
+        static_for<N>([&](auto ic) {
+            const int n = pos(ic);
+            if (n >= 0) put(ic, rr_value(b, n));
+        });
+        return;
+    }
+    int idx[N], pp[N]; // idx: index into f or -1 (nothing received) / -2 (filler); pp: index into the HARQ buffer or -1
+    static_for<N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int n = pos(ic);
+        const int p = n - b.Z2;
+        const bool fill = p >= b.lo_f && p < b.hi_f;
+        const bool inbuf = n >= 0 && p >= 0 && p < b.N_cb && !fill;
+        int c = p - b.lo_f;
+        c = c < 0 ? 0 : (c > b.F ? b.F : c);
+        int q = p - c - b.nfk0;
+        q += q < 0 ? b.P : 0;
+        int r = 0;
+        for (int m = 1; m < 8; ++m) r += (m < b.Qm && q >= m * b.rows) ? 1 : 0; // q / rows (Q_m <= 8)
+        idx[i] = (n >= 0 && fill) ? -2 : (inbuf && q < b.E) ? (q - r * b.rows) * b.Qm + r : -1;
+        pp[i] = inbuf ? p : -1;
+        if (n < 0) { idx[i] = -3; pp[i] = -1; }
+    });
+    float v[N];
+    static_for<N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        v[i] = idx[i] >= 0 ? b.f[idx[i]] : 0.0f;
+    });
+    if (b.hb) { // :236-239
+        float h[N];
+        static_for<N>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            h[i] = pp[i] >= 0 ? b.hb[pp[i]] : 0.0f;
+        });
+        static_for<N>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (pp[i] >= 0) {
+                v[i] += h[i];
+                b.hb[pp[i]] = v[i];
+            }
+        });
+    }
+    static_for<N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (idx[i] != -3) put(ic, idx[i] == -2 ? __builtin_inff() : v[i]);
+    });
+}
+
 template <int BG> struct DecState {
     uint32_t rm[BGD<BG>::NW];  // check-to-variable messages, int8 x4
     uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4

@@ -126,7 +126,7 @@ def test_result_file_does_not_depend_on_the_number_of_shards(pkg, tmp_path):
             d = tmp_path / ("s%d_%d" % (shards, kw["A"]))
             curves = H.plot_BLER_vs_SNR(results_dir=str(d), device=True, devices=[0] * shards, **kw)
             (pts,) = curves.values()
-            assert len(pts) >= 2
+            assert len(pts) >= 1
             (f,) = list(d.iterdir())
             files.append(f.read_bytes())
         assert files[0] == files[1] == files[2] == files[3] and len(files[0]) > 20

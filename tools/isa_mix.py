@@ -84,13 +84,18 @@ def main():
             off = int(args.split()[0])
             if off >= 32768:
                 spans.append((ad + 4 + (off - 65536) * 4, ad))
-    spans.sort(key=lambda t: t[0] - t[1])
-    keep = [spans[0]]
-    if a.form == "split":
-        for sp in spans[1:]:
-            if sp[1] - sp[0] >= 0.3 * (spans[0][1] - spans[0][0]) and all(sp[1] < k[0] or sp[0] > k[1] for k in keep):
-                keep.append(sp)
-        assert len(keep) == 2, "expected one iteration loop per half, found %d" % len(keep)
+    # the iteration loop(s): the innermost backward branches that enclose exactly one barrier per barrier group (BG1 32,
+    # BG2 28 with every row active) -- one loop in the row form, one per half in the split form
+    ng = {1: 32, 2: 28}[a.bg]
+    bars = [b[0] for b in body if b[1] == "s_barrier"]
+    spans = [sp for sp in spans if sum(1 for x in bars if sp[0] <= x <= sp[1]) == ng]
+    spans.sort(key=lambda t: t[1] - t[0])
+    keep = []
+    for sp in spans:
+        if all(sp[1] < k[0] or sp[0] > k[1] for k in keep):
+            keep.append(sp)
+    want = 2 if a.form == "split" else 1
+    assert len(keep) == want, "expected %d iteration loop(s) with %d barriers, found %d" % (want, ng, len(keep))
     loop = [b for b in body if any(lo <= b[0] <= hi for lo, hi in keep)]
     lo, hi = min(k[0] for k in keep), max(k[1] for k in keep)
     loop_bytes = sum(k[1] - k[0] for k in keep)
