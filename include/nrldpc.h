@@ -164,18 +164,6 @@ typedef struct nrldpc_tb_params {
 int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
                             void* d_cw_llr, int32_t out_dtype, void* stream);
 
-/* Rate recovery AND the decoder core in one call -- NRLDPCDecoder.m:143-268 (code_block_concatenation, bit_interleaving,
- * bit_selection incl. the HARQ buffer, LDPC_coding) for n_tb transport blocks: d_g_tilde [n_tb][G] f32 -> d_c_hat
- * [n_tb*C][K] hard bits (d_iters_out nullable: [n_tb*C]).  For the lifting sizes served by the compile-time-Z kernels the
- * decoder's prologue gathers its input from g_tilde itself: one launch, no intermediate LLR array in HBM (a code block's
- * 2Z+N values never leave the chip between the gather and the last iteration); other sizes run nrldpc_rate_recover_dev
- * into a staging buffer of the handle, then the decoder.  Either way the result is that of nrldpc_rate_recover_dev with
- * NRLDPC_LLR_F32 output followed by nrldpc_decode_dev, bit for bit.  h must have been created for p's (BG, Z);
- * its llr_dtype does not matter here.  Asynchronous on `stream`. */
-int nrldpc_decode_tb_dev(nrldpc_handle h, const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
-                         uint8_t* d_c_hat, int32_t* d_iters_out, void* stream);
-int nrldpc_decode_tb_is_fused(nrldpc_handle h); /* 1: nrldpc_decode_tb_dev is one launch for this handle's (BG, Z); 0: two */
-
 /* CRC stages: replaces code_block_segmentation + crc_calculation of the decoder (NRLDPCDecoder.m:271-340).
  * d_c_hat: [n_tb*C][K] hard bits from nrldpc_decode_dev.  d_b_hat: [n_tb][B] bytes (a_hat = first A of a row).
  * d_ok: [n_tb], 0 where the reference returns [] (TB CRC or any CB CRC failed).  d_cb_pass (nullable):

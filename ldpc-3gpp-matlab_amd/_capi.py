@@ -68,7 +68,7 @@ def tb_params(p):
     return t
 
 
-EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev", "nrldpc_decode_tb_dev", "nrldpc_decode_tb_is_fused", "nrldpc_crc_check_dev", "nrldpc_crc_check_harq_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
+EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev",  "nrldpc_crc_check_dev", "nrldpc_crc_check_harq_dev", "nrldpc_crc_attach_dev", "nrldpc_rate_match_dev", "nrldpc_create", "nrldpc_destroy", "nrldpc_get_dims", "nrldpc_decode", "nrldpc_decode_dev",
            "nrldpc_decode_multi_dev", "nrldpc_quantise_llr", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version", "nrldpc_build_id", "nrldpc_kernel_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
@@ -124,8 +124,6 @@ def load():
     L.nrldpc_encode.argtypes = [vp, vp, i32, vp]
     L.nrldpc_encode_dev.argtypes = [vp, vp, i32, vp, vp]
     L.nrldpc_rate_recover_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, i32, vp]
-    L.nrldpc_decode_tb_dev.argtypes = [vp, C.POINTER(TbParams), vp, i32, vp, vp, vp, vp]
-    L.nrldpc_decode_tb_is_fused.argtypes = [vp]
     L.nrldpc_crc_check_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, vp, vp]
     L.nrldpc_crc_check_harq_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp, vp, vp, i32, vp]
     L.nrldpc_awgn_llr_dev.argtypes = [vp, C.c_int64, i32, C.c_float, C.c_uint64, C.c_uint64, vp, vp]
@@ -236,17 +234,6 @@ class Codec:
     def decode_dev(self, d_llr, batch, d_hard, d_iters=None, d_app=None, stream=0):
         check(self._lib.nrldpc_decode_dev(self._h, _ptr(d_llr), int(batch), _ptr(d_hard), _ptr(d_iters),
                                           _ptr(d_app), C.c_void_p(stream)))
-
-    def decode_tb_is_fused(self):
-        """True when decode_tb_dev is ONE launch for this codec (a compile-time-Z kernel serves its lifting size)."""
-        return bool(self._lib.nrldpc_decode_tb_is_fused(self._h))
-
-    def decode_tb_dev(self, p, d_g_tilde, n_tb, d_harq, d_c_hat, d_iters=None, stream=0):
-        """nrldpc_decode_tb_dev: rate recovery + decoder core in one call (one launch for the compile-time-Z lifting
-        sizes): g_tilde [n_tb][G] f32 -> hard bits [n_tb*C][K]; d_harq None = I_HARQ 0."""
-        t = p if isinstance(p, TbParams) else tb_params(p)
-        check(self._lib.nrldpc_decode_tb_dev(self._h, C.byref(t), _ptr(d_g_tilde), int(n_tb), _ptr(d_harq), _ptr(d_c_hat),
-                                             _ptr(d_iters), C.c_void_p(stream)))
 
     def encode_dev(self, d_info, batch, d_cw, stream=0):
         check(self._lib.nrldpc_encode_dev(self._h, _ptr(d_info), int(batch), _ptr(d_cw), C.c_void_p(stream)))

@@ -325,7 +325,6 @@ struct nrldpc_codec {
     int p0_shift = 0, step_row[3] = {0, 0, 0}, step_col[3] = {0, 0, 0}, step_shift[3] = {0, 0, 0};
     int step_nk[3] = {0, 0, 0}, step_kcol[3][3] = {}, step_kshift[3][3] = {}; // already-known core blocks in that row
     // host-entry staging
-    DevBuf<float> s_rr; // nrldpc_decode_tb_dev's staging buffer (lifting sizes without the fused prologue)
     DevBuf<char> s_llr;
     DevBuf<int8_t> s_q; // int8 chunks of the pipelined host path, one region per slot
     DevBuf<uint8_t> s_hard, s_bits;
@@ -582,7 +581,7 @@ void nrldpc_destroy(nrldpc_handle h) {
     DeviceScope scope(h->cfg.device_id);
     h->d_rot.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
-    h->s_rr.release(); h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
+    h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
     for (int i = 0; i < 3; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
@@ -1142,60 +1141,6 @@ int nrldpc_rate_recover_dev(const nrldpc_tb_params* p, const float* d_g_tilde, i
     hipError_t e = nrldpc::launch_rate_recover(a, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hipfail(e, "rate-recovery kernel launch");
     return NRLDPC_OK;
-}
-
-int nrldpc_decode_tb_is_fused(nrldpc_handle h) {
-    if (!h) return 0;
-    static const bool no_fuse = getenv("NRLDPC_NO_FUSED_RR") != nullptr;
-    return (nrldpc::decode_supports_rr(h->sched.g.bg, h->sched.Z) && !no_fuse) ? 1 : 0;
-}
-
-int nrldpc_decode_tb_dev(nrldpc_handle h, const nrldpc_tb_params* p, const float* d_g_tilde, int32_t n_tb, float* d_harq,
-                         uint8_t* d_c_hat, int32_t* d_iters_out, void* stream) {
-    NRLDPC_API_BEGIN
-    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
-    int rc = check_tb_params(p);
-    if (rc) return rc;
-    if (n_tb < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
-    if (n_tb == 0) return NRLDPC_OK;
-    if (!d_c_hat) return fail(NRLDPC_ERR_ARG, "null pointer");
-    const nrldpc::Schedule& s = h->sched;
-    if (p->bg != s.g.bg || p->Z != s.Z || p->N + 2 * p->Z != s.g.ncols * s.Z || p->K != s.g.kb * s.Z)
-        return fail(NRLDPC_ERR_ARG, "transport-block parameters do not belong to this codec's (BG, Z)");
-    if ((long long)n_tb * p->C > 0x7fffffffLL) return fail(NRLDPC_ERR_ARG, "too many code blocks");
-    const int batch = n_tb * p->C;
-    DEVICE_SCOPE(h);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (nrldpc_decode_tb_is_fused(h)) { // NRLDPC_NO_FUSED_RR in the environment: always the two-launch path (A/B)
-        // ONE launch: the decoder's prologue gathers its input from g_tilde (and updates the HARQ buffer) itself.  The
-        // argument block travels through the ring of pinned / device table slots (as nrldpc_decode_multi_dev's tables).
-        nrldpc::RmArgs ra;
-        rc = make_rm_args(p, d_g_tilde, n_tb, d_harq, nullptr, NRLDPC_LLR_F32, &ra);
-        if (rc) return rc;
-        nrldpc_codec::MultiSlot& m = h->multi[h->multi_next];
-        h->multi_next = (h->multi_next + 1) % nrldpc_codec::kMultiSlots;
-        if (!m.done) HIP_TRY(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
-        if (m.used) HIP_TRY(hipEventSynchronize(m.done));
-        HIP_TRY(m.pin.reserve(sizeof ra));
-        HIP_TRY(m.dev.reserve(sizeof ra));
-        memcpy(m.pin.p, &ra, sizeof ra);
-        HIP_TRY(hipMemcpyAsync(m.dev.p, m.pin.p, sizeof ra, hipMemcpyHostToDevice, st));
-        nrldpc::DecArgs a = make_dec_args(h, nullptr, batch, d_c_hat, d_iters_out, nullptr, NRLDPC_K_RR);
-        a.rr = reinterpret_cast<const nrldpc::RmArgs*>(m.dev.p);
-        begin_timing(h, st);
-        hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, st);
-        end_timing(h, st);
-        (void)hipEventRecord(m.done, st); // also on a failed launch: the copy above is in flight
-        m.used = true;
-        if (e != hipSuccess) return hipfail(e, "decode kernel launch (fused rate recovery)");
-        return NRLDPC_OK;
-    }
-    // lifting sizes served by the run-time-Z kernel: rate recovery into a float staging buffer of the handle, then the decode
-    HIP_TRY(h->s_rr.reserve((size_t)batch * s.g.ncols * s.Z));
-    rc = nrldpc_rate_recover_dev(p, d_g_tilde, n_tb, d_harq, h->s_rr.p, NRLDPC_LLR_F32, stream);
-    if (rc) return rc;
-    return decode_launch(h, h->s_rr.p, batch, d_c_hat, d_iters_out, nullptr, st, NRLDPC_K_F32);
-    NRLDPC_API_END
 }
 
 static int crc_check_common(const nrldpc_tb_params* p, const uint8_t* d_c_hat, int32_t n_tb, uint8_t* d_b_hat, int32_t* d_ok,

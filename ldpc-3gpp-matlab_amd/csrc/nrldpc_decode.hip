@@ -37,10 +37,7 @@ __device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zb, 
     constexpr bool HAS_EXT = (L >= 4);
     constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
     constexpr int ce0 = G::core_base(L);
-    // ring size in bytes as a VECTOR register value: any VALU op with a scalar operand issues at 4 cycles on gfx950, so
-    // the wrap's subtraction runs at the full rate this way (10 instead of 12 cycles of address arithmetic per edge)
-    uint32_t zsb = (uint32_t)a.Z * (uint32_t)a.sbw;
-    asm volatile("" : "+v"(zsb));
+    const uint32_t zsb = (uint32_t)a.Z * (uint32_t)a.sbw;
 
     float t[ncore];
     uint32_t ad[ncore];
@@ -72,17 +69,16 @@ __device__ __forceinline__ void layer(DecState<BG>& st, char* lds, uint32_t zb, 
         S ^= fbits(lam);
     }
     // magnitudes carrying the row's sign parity; the edge's own sign is xor-ed in per edge
-    // M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
-    const float M1 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag(a, m1)), S, 0x80000000u, 0xF8));
-    const float M2 = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(scale_mag(a, m2)), S, 0x80000000u, 0xF8));
+    const uint32_t Sm = S & 0x80000000u;
+    const float M1 = __uint_as_float(fbits(scale_mag(a, m1)) | Sm);
+    const float M2 = __uint_as_float(fbits(scale_mag(a, m2)) | Sm);
     static_for<ncore>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);
         constexpr int ce = ce0 + j;
         const float tj = t[j];
         const float mag = (fabsf(tj) == m1) ? M2 : M1;
-        // mag ^ (t & signbit) in one v_bitop3_b32 (0x78 = a ^ (b & c))
-        const float r = __uint_as_float(__builtin_amdgcn_bitop3_b32(fbits(mag), fbits(tj), 0x80000000u, 0x78));
+        const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
         f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
         *reinterpret_cast<float*>(lds + ad[j] + 4 * c) = tj + r;
     });
@@ -330,8 +326,6 @@ bool has_z64_kernel(int bg, int Z) {
 #undef NRLDPC_Z64_CASE
     return false;
 }
-
-bool decode_supports_rr(int bg, int Z) { return has_z64_kernel(bg, Z); } // every build of the compile-time-Z kernels
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
     const bool force_generic = force_generic_env();

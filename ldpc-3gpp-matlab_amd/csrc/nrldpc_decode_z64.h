@@ -694,28 +694,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
                 f32_to_byte<i & 3>(st.xq[i >> 2], ingest(val(xe[i]), a.scale, false));
             });
         };
-        // llr_kind == NRLDPC_K_RR: no LLR array -- this prologue IS the rate recovery (rr_value: NRLDPCDecoder.m:143-242,
-        // 262-264 per position, straight from the demodulator's LLRs), one ring position per thread and column.  With a HARQ
-        // buffer every position of the code block is visited, also the columns a pruned layer count never reads: the
-        // buffer has to hold them for the retransmissions to come.
-        auto ingest_rr = [&]() {
-            const RrBlock rb = rr_block(a.rr, cw);
-            rr_gather<G::NC>(rb, [&](auto cc) { return decltype(cc)::value * ZC + z; }, [&](auto cc, float v) {
-                constexpr int c = decltype(cc)::value;
-                const float q = ingest(v, a.scale, true);
-                *reinterpret_cast<float*>(home + c * G::CS) = q;
-                if (w == 0) *reinterpret_cast<float*>(home + c * G::CS + ZC * 4) = q; // mirror of block 0
-            });
-            rr_gather<G::NEXT>(rb, [&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                return (rb.hb || (FULL && NL == G::ROWS) || i < next_used) ? (G::NC + i) * ZC + z : -1;
-            }, [&](auto ic, float v) {
-                constexpr int i = decltype(ic)::value;
-                f32_to_byte<i & 3>(st.xq[i >> 2], ingest(v, a.scale, false));
-            });
-        };
-        if (a.llr_kind == NRLDPC_K_RR) ingest_rr();
-        else if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
         else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
         if (app_row) {
             static_for<G::NEXT>([&](auto ic) {

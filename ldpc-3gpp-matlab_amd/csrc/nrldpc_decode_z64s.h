@@ -191,25 +191,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                 });
             }
         };
-        if (a.llr_kind == NRLDPC_K_RR) {
-            // no LLR array: this prologue IS the rate recovery (rr_value, nrldpc_device.h); the halves take alternate columns
-            const RrBlock rb = rr_block(a.rr, cw);
-            rr_gather<(G::NC + 1) / 2>(rb, [&](auto kc) {
-                const int c = 2 * decltype(kc)::value + half;
-                return c < G::NC ? c * ZC + z : -1;
-            }, [&](auto kc, float v) {
-                const int c = 2 * decltype(kc)::value + half;
-                const float q = ingest(v, a.scale, true);
-                char* home = lds + G::GUARD + 4 * z + c * G::CS;
-                *reinterpret_cast<float*>(home) = q;
-                if (w == 0) *reinterpret_cast<float*>(home + ZC * 4) = q;
-            });
-            // extension columns of rows a pruned layer count leaves out: never read, but a HARQ buffer has to hold them
-            if (rb.hb && half == 0) {
-                rr_gather<G::ROWS - NL>(rb, [&](auto ic) { return (G::NC + NL + decltype(ic)::value - 4) * ZC + z; },
-                                        [&](auto, float) {});
-            }
-        } else if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
         else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
     }
 
@@ -245,19 +227,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                 f32_to_byte<i & 3>(st.xq[i >> 2], ingest(v, a.scale, false));
             });
         };
-        if (a.llr_kind == NRLDPC_K_RR) {
-            const RrBlock rb = rr_block(a.rr, cw);
-            rr_gather<NL - 4>(rb, [&](auto ic) {
-                constexpr int L = 4 + decltype(ic)::value;
-                return O::mine(L) ? (G::NC + L - 4) * ZC + z : -1;
-            }, [&](auto ic, float v) {
-                constexpr int L = 4 + decltype(ic)::value;
-                if constexpr (O::mine(L)) {
-                    constexpr int xi = O::ext_index(L);
-                    f32_to_byte<xi & 3>(st.xq[xi >> 2], ingest(v, a.scale, false));
-                }
-            });
-        } else if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});
+        if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});
         else load_ext(std::integral_constant<int, NRLDPC_K_F32>{});
         if constexpr (XF) {
             static_for<O::NEXT>([&](auto ic) {

@@ -207,123 +207,6 @@ __device__ __forceinline__ float scale_mag(const DecArgs& a, float m) {
     return __builtin_amdgcn_fmed3f(y, 8388608.0f, 8388608.0f + 127.0f) - 8388608.0f;
 }
 
-// ---- rate recovery inside the decoder's prologue (llr_kind == NRLDPC_K_RR) ------------------------------------------------
-// One decoder-input value straight from the demodulator's LLRs g_tilde: code_block_concatenation + bit_interleaving +
-// bit_selection with soft combining of repetitions + the HARQ buffer + the core's input conventions
-// (NRLDPCDecoder.m:143-242, 262-264), the arithmetic of nrldpc_rate_recover_kernel (nrldpc_ratematch.hip) per position, in
-// the same fp32 summation order (repetitions in ascending k, then the buffer).  The arguments live in device memory and are
-// read with scalar loads (wave-uniform addresses).
-struct RrBlock {
-    const float* f; // g_tilde segment of this code block
-    float* hb;      // its HARQ buffer row or null
-    int lo_f, hi_f, F, P, nfk0, E, rows, Qm, N_cb, Z2;
-};
-typedef const RmArgs __attribute__((address_space(4))) * rr_ctab_t;
-__device__ __forceinline__ RrBlock rr_block(const RmArgs* rrp, int blk) {
-    rr_ctab_t a = reinterpret_cast<rr_ctab_t>(reinterpret_cast<uintptr_t>(rrp));
-    RrBlock b;
-    const int C = a->C, tb = blk / C, r = blk - tb * C;
-    b.Z2 = 2 * a->Z;
-    b.N_cb = a->N_cb; b.Qm = a->Qm;
-    b.lo_f = a->Kp - b.Z2 > 0 ? a->Kp - b.Z2 : 0;
-    b.hi_f = a->K - b.Z2;
-    const int f_hi = b.hi_f < b.N_cb ? b.hi_f : b.N_cb;
-    b.F = f_hi > b.lo_f ? f_hi - b.lo_f : 0;
-    b.P = b.N_cb - b.F;
-    int c0 = a->k0 - b.lo_f;
-    c0 = c0 < 0 ? 0 : (c0 > b.F ? b.F : c0);
-    b.nfk0 = a->k0 - c0;
-    b.E = a->E[r];
-    b.rows = b.E > 0 ? b.E / b.Qm : 1;
-    b.f = a->g + (size_t)tb * a->G + a->off[r];
-    b.hb = a->harq ? a->harq + (size_t)blk * b.N_cb : nullptr;
-    return b;
-}
-// n: index into the decoder's input (0 .. ncols*Z-1); the first 2Z positions are the punctured columns (:262)
-__device__ __forceinline__ float rr_value(const RrBlock& b, int n) {
-    const int p = n - b.Z2;
-    if (p < 0) return 0.0f;
-    if (p >= b.lo_f && p < b.hi_f) return __builtin_inff(); // filler (:224, :264)
-    if (p >= b.N_cb) return 0.0f;                            // beyond the (limited) circular buffer
-    int c = p - b.lo_f;
-    c = c < 0 ? 0 : (c > b.F ? b.F : c);
-    int q = p - c - b.nfk0; // index among the buffer's non-filler positions counted from k_0
-    q += q < 0 ? b.P : 0;
-    float val = 0.0f;
-    for (int k = q; k < b.E; k += b.P) { // soft combining of repetitions, ascending k (:229-231)
-        int i = 0;
-        for (int m = 1; m < b.Qm; ++m) i += (k >= m * b.rows); // k / rows
-        val += b.f[(k - i * b.rows) * b.Qm + i];               // e(i*rows + j) = f(i + j*Qm)  (:191-195)
-    }
-    if (b.hb) { // :236-239
-        val += b.hb[p];
-        b.hb[p] = val;
-    }
-    return val;
-}
-
-// The same for N positions of one thread at once, arranged so that the prologue does not become a chain of dependent memory
-// round trips: without repetition (E_r <= non-filler positions of the buffer: a position takes one e(k) or none) all
-// index arithmetic comes first, then all loads are issued back to back, then the HARQ buffer's, then the values are
-// handed over.  pos(i) = decoder-input index of item i (negative: skip the item), put(i, value).  With repetition the
-// per-position walk of rr_value is used (rare: code rates below the mother code's).
-template <int N, class PosF, class PutF>
-__device__ __forceinline__ void rr_gather_n(const RrBlock& b, PosF&& pos, PutF&& put);
-template <int N, class PosF, class PutF>
-__device__ __forceinline__ void rr_gather(const RrBlock& b, PosF&& pos, PutF&& put) {
-    if constexpr (N > 0) rr_gather_n<N>(b, pos, put);
-}
-template <int N, class PosF, class PutF>
-__device__ __forceinline__ void rr_gather_n(const RrBlock& b, PosF&& pos, PutF&& put) {
-    if (b.E > b.P) { // wave-uniform
-        static_for<N>([&](auto ic) {
-            const int n = pos(ic);
-            if (n >= 0) put(ic, rr_value(b, n));
-        });
-        return;
-    }
-    int idx[N], pp[N]; // idx: index into f or -1 (nothing received) / -2 (filler); pp: index into the HARQ buffer or -1
-    static_for<N>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int n = pos(ic);
-        const int p = n - b.Z2;
-        const bool fill = p >= b.lo_f && p < b.hi_f;
-        const bool inbuf = n >= 0 && p >= 0 && p < b.N_cb && !fill;
-        int c = p - b.lo_f;
-        c = c < 0 ? 0 : (c > b.F ? b.F : c);
-        int q = p - c - b.nfk0;
-        q += q < 0 ? b.P : 0;
-        int r = 0;
-        for (int m = 1; m < 8; ++m) r += (m < b.Qm && q >= m * b.rows) ? 1 : 0; // q / rows (Q_m <= 8)
-        idx[i] = (n >= 0 && fill) ? -2 : (inbuf && q < b.E) ? (q - r * b.rows) * b.Qm + r : -1;
-        pp[i] = inbuf ? p : -1;
-        if (n < 0) { idx[i] = -3; pp[i] = -1; }
-    });
-    float v[N];
-    static_for<N>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        v[i] = idx[i] >= 0 ? b.f[idx[i]] : 0.0f;
-    });
-    if (b.hb) { // :236-239
-        float h[N];
-        static_for<N>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            h[i] = pp[i] >= 0 ? b.hb[pp[i]] : 0.0f;
-        });
-        static_for<N>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (pp[i] >= 0) {
-                v[i] += h[i];
-                b.hb[pp[i]] = v[i];
-            }
-        });
-    }
-    static_for<N>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if (idx[i] != -3) put(ic, idx[i] == -2 ? __builtin_inff() : v[i]);
-    });
-}
-
 template <int BG> struct DecState {
     uint32_t rm[BGD<BG>::NW];  // check-to-variable messages, int8 x4
     uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4

@@ -6,7 +6,6 @@
 
 #define NRLDPC_K_F32 0
 #define NRLDPC_K_F16 1
-#define NRLDPC_K_RR 2 // no LLR array: the decoder's prologue performs rate recovery itself (DecArgs::rr, nrldpc_decode_tb_dev)
 
 #ifndef NRLDPC_GEN_THREADS_BG1
 #define NRLDPC_GEN_THREADS_BG1 512 // workgroup size cap of the run-time-Z kernel for BG1
@@ -23,11 +22,8 @@
 
 namespace nrldpc {
 
-struct RmArgs;
 struct DecArgs {
-    const void* llr;     // [batch][ncols*Z] f32 or f16; unused when llr_kind == NRLDPC_K_RR
-    const RmArgs* rr;    // llr_kind == NRLDPC_K_RR: device copy of the rate-recovery arguments (codeword b = code block b of
-                         // its n_tb * C); the compile-time-Z kernels gather their input from g_tilde themselves
+    const void* llr;     // [batch][ncols*Z] f32 or f16
     uint8_t* hard;       // [batch][kb*Z]
     int32_t* iters;      // [batch] or null
     float* app;          // [batch][ncols*Z] or null
@@ -40,7 +36,6 @@ struct DecArgs {
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream);
 bool has_z64_kernel(int bg, int Z); // a compile-time-Z specialisation serves this (BG, Z)
-bool decode_supports_rr(int bg, int Z); // ... and so does the fused rate-recovery prologue (NRLDPC_K_RR)
 // many (Z) configurations of one base graph in one launch of the run-time-Z kernel: d_tab[nb] argument blocks,
 // d_start[nb+1] first workgroup of each configuration (d_start[nb] = grid)
 hipError_t launch_decode_multi(int bg, int llr_kind, const DecArgs* d_tab, const int32_t* d_start, int nb, int grid,

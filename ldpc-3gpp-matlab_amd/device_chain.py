@@ -17,14 +17,9 @@ class DeviceDecodeChain:
     code_block_CRC_passed flags (`cb_pass`); reset() clears them (:343-356).  CBGTI of `params` is honoured (:304)."""
 
     def __init__(self, params: NRLDPC, iterations=50, I_HARQ=0, alpha=None, llr_scale=0, prune_layers=True,
-                 llr_dtype=np.float16, device_id=0, beta=0.0, fused=None):
-        """fused: rate recovery inside the decoder's launch (nrldpc_decode_tb_dev; the value the decoder ingests is the
-        fp32 sum the reference's loops form).  fused=False keeps the two launches with an intermediate LLR array of
-        `llr_dtype` in HBM (fp16 by default: that path rounds the sum to fp16 before the decoder quantises it).
-        None (default): fused where the codec does it in one launch (the compile-time-Z lifting sizes)."""
+                 llr_dtype=np.float16, device_id=0, beta=0.0):
         import torch
         self.torch = torch
-        self.fused = fused
         params.validate()
         self.p = params
         self.iterations, self.I_HARQ = int(iterations), int(I_HARQ)
@@ -83,6 +78,10 @@ class DeviceDecodeChain:
             self.b_hat = torch.zeros((n_tb, p.B), dtype=torch.uint8, device=self.dev)
             if self.I_HARQ:
                 self.harq = torch.zeros((n_tb, C_, p.N_cb), dtype=torch.float32, device=self.dev)
+        tdt = torch.float16 if self.llr_dtype == np.float16 else torch.float32
+        cw_llr = torch.empty((n_tb * C_, ncwz), dtype=tdt, device=self.dev)
+        rate_recover_dev(t, g_tilde.data_ptr(), n_tb, self.harq.data_ptr() if self.I_HARQ else None,
+                         cw_llr.data_ptr(), LLR_F16 if tdt == torch.float16 else LLR_F32, stream)
         rows = 46 if p.BG == 1 else 42
         n_layers = rows
         if self.prune:
@@ -92,17 +91,7 @@ class DeviceDecodeChain:
         codec = self._codec_for(n_layers)
         c_hat = torch.empty((n_tb * C_, p.K), dtype=torch.uint8, device=self.dev)
         iters = torch.empty(n_tb * C_, dtype=torch.int32, device=self.dev)
-        if self.fused if self.fused is not None else codec.decode_tb_is_fused():
-            # NRLDPCDecoder.m:143-268 in ONE call (nrldpc_decode_tb_dev): the decoder's prologue gathers its input from
-            # g_tilde (and updates the HARQ buffer) itself; no intermediate LLR array
-            codec.decode_tb_dev(t, g_tilde.data_ptr(), n_tb, self.harq.data_ptr() if self.I_HARQ else None,
-                                c_hat.data_ptr(), iters.data_ptr(), stream)
-        else:
-            tdt = torch.float16 if self.llr_dtype == np.float16 else torch.float32
-            cw_llr = torch.empty((n_tb * C_, ncwz), dtype=tdt, device=self.dev)
-            rate_recover_dev(t, g_tilde.data_ptr(), n_tb, self.harq.data_ptr() if self.I_HARQ else None,
-                             cw_llr.data_ptr(), LLR_F16 if tdt == torch.float16 else LLR_F32, stream)
-            codec.decode_dev(cw_llr.data_ptr(), n_tb * C_, c_hat.data_ptr(), iters.data_ptr(), None, stream)
+        codec.decode_dev(cw_llr.data_ptr(), n_tb * C_, c_hat.data_ptr(), iters.data_ptr(), None, stream)
         ok = torch.empty(n_tb, dtype=torch.int32, device=self.dev)
         crc_check_harq_dev(t, c_hat.data_ptr(), n_tb, self.b_hat.data_ptr(), ok.data_ptr(), self.cb_pass.data_ptr(),
                            p.CBGTI_flags, self.I_HARQ != 0, stream)

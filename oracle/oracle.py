@@ -107,8 +107,9 @@ def decode_bp_flood(bg, Z, llr, max_iter, n_layers=0, nthreads=0, want_app=False
 
 def rate_recover(Z, C_, K, K_prime, N, N_cb, k_0, Q_m, G, E_r, g_tilde, harq=None):
     """Literal NRLDPCDecoder.m:143-242,262-264 in fp32; returns [n_tb*C][2Z+N] (harq updated in place)."""
-    g_tilde = np.ascontiguousarray(g_tilde, np.float32).reshape(-1, G)
-    n_tb = g_tilde.shape[0]
+    g_tilde = np.ascontiguousarray(g_tilde, np.float32)
+    n_tb = g_tilde.shape[0] if g_tilde.ndim == 2 else g_tilde.size // max(G, 1)  # G == 0 (testbench.m can draw it): shape [n_tb][0]
+    g_tilde = g_tilde.reshape(n_tb, G)
     E = np.ascontiguousarray(E_r, np.int32)
     out = np.zeros((n_tb * C_, 2 * Z + N), np.float32)
     if harq is not None:

@@ -205,46 +205,3 @@ def test_channel_kernel_matches_numpy_restatement(pkg, Q_m, esn0):
     with pytest.raises(pkg.NRLDPCError):
         pkg.awgn_llr_dev(d_g.data_ptr(), 7, 2, 0.0, 1, 0, out.data_ptr())
 
-
-@pytest.mark.parametrize("kw", CASES + [dict(BG=1, A=8424, G=9478, Q_m=2), dict(BG=2, A=3824, G=7648, Q_m=4, rv_id=2),
-                                        dict(BG=1, A=8424, G=60000, Q_m=6, rv_id=3)])  # pruned layers; repetition at Z = 384
-def test_fused_rate_recovery_equals_the_two_launch_path(pkg, orc, kw):
-    """nrldpc_decode_tb_dev (the gather writes the decoder's LDS rings directly, no intermediate LLR
-    array) against nrldpc_rate_recover_dev with fp32 output followed by nrldpc_decode_dev: hard bits, iteration counts
-    and the HARQ buffer bit for bit, over two accumulating steps; the first step's rate-recovered values themselves are
-    the literal loops' (oracle), checked through the HARQ buffer.  Lifting sizes without a compile-time-Z kernel take
-    the staging-buffer fallback inside the same entry point."""
-    import torch
-    p = pkg.NRLDPC(**kw)
-    p.validate()
-    rng = np.random.default_rng(p.A * 7 + p.G)
-    n_tb = 3
-    nl = p.active_layers()
-    codec = pkg.Codec(p.BG, p.Z_c, max_iter=6, n_layers=nl, early_term=True, llr_dtype=np.float32)
-    harq_f = torch.zeros((n_tb, p.C, p.N_cb), dtype=torch.float32, device="cuda")
-    harq_u = torch.zeros_like(harq_f)
-    harq_o = np.zeros((n_tb, p.C, p.N_cb), np.float32)
-    s = torch.cuda.current_stream().cuda_stream
-    for step in range(2):
-        g = (3 * rng.standard_normal((n_tb, p.G)) + 1.0).astype(np.float32)
-        d_g = torch.from_numpy(g).cuda()
-        hard_f = torch.zeros((n_tb * p.C, p.K), dtype=torch.uint8, device="cuda")
-        it_f = torch.zeros(n_tb * p.C, dtype=torch.int32, device="cuda")
-        codec.decode_tb_dev(p, d_g.data_ptr(), n_tb, harq_f.data_ptr(), hard_f.data_ptr(), it_f.data_ptr(), s)
-        llr = torch.empty((n_tb * p.C, 2 * p.Z_c + p.N), dtype=torch.float32, device="cuda")
-        pkg.rate_recover_dev(p, d_g.data_ptr(), n_tb, harq_u.data_ptr(), llr.data_ptr(), stream=s)
-        hard_u = torch.zeros_like(hard_f)
-        it_u = torch.zeros_like(it_f)
-        codec.decode_dev(llr.data_ptr(), n_tb * p.C, hard_u.data_ptr(), it_u.data_ptr(), None, s)
-        torch.cuda.synchronize()
-        orc.rate_recover(p.Z_c, p.C, p.K, int(p.K_prime), p.N, p.N_cb, p.k_0, p.Q_m, p.G, p.E_r, g, harq_o)
-        assert (harq_f == harq_u).all() and (harq_f.cpu().numpy() == harq_o).all(), (kw, step)
-        assert (hard_f == hard_u).all() and (it_f == it_u).all(), (kw, step)
-    # without a HARQ buffer
-    hard_f.zero_(); hard_u.zero_()
-    codec.decode_tb_dev(p, d_g.data_ptr(), n_tb, None, hard_f.data_ptr(), it_f.data_ptr(), s)
-    pkg.rate_recover_dev(p, d_g.data_ptr(), n_tb, None, llr.data_ptr(), stream=s)
-    codec.decode_dev(llr.data_ptr(), n_tb * p.C, hard_u.data_ptr(), it_u.data_ptr(), None, s)
-    torch.cuda.synchronize()
-    assert (hard_f == hard_u).all() and (it_f == it_u).all(), kw
-    codec.close()

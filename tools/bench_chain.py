@@ -89,18 +89,15 @@ def run(name, n_tb, harq, **props):
     tx = H.modulate_t(g, props["Q_m"])
     rx = tx + (N0 / 2) ** 0.5 * torch.view_as_complex(torch.randn(tx.shape + (2,), device="cuda", dtype=torch.float64, generator=gen))
     g_noisy = H.demodulate_llr_t(rx, props["Q_m"], N0).float().contiguous()
-    for fused in (True, False):  # rate recovery inside the decoder's launch (nrldpc_decode_tb_dev) / as a launch of its own
-        chain = DC.DeviceDecodeChain(p, iterations=25, llr_dtype=np.float16, fused=fused)
-        a_hat, okc, iters = chain.step(g_noisy)
-        ms = timed(lambda: chain.step(g_noisy), reps=5)
-        r = {"config": name, "stage": "receive chain (%s + CRC)" % ("rate recovery fused into the decode launch, parity-check stop" if fused else
-                                                                     "rate recovery -> fp16 LLR array -> decode with parity-check stop"),
-             "fused": fused, "n_tb": n_tb, "C": C, "Z": Z,
-             "G": G, "ms": ms, "EsN0_dB": esn0, "tb_ok_fraction": float(okc.float().mean()), "mean_iters": float(iters.float().mean()),
-             "tb_per_s": n_tb / ms * 1e3, "payload_Gbit_s": n_tb * A / ms / 1e6}
-        print(r, flush=True)
-        out.append(r)
-        chain.close()
+    chain = DC.DeviceDecodeChain(p, iterations=25, llr_dtype=np.float16)
+    a_hat, okc, iters = chain.step(g_noisy)
+    ms = timed(lambda: chain.step(g_noisy), reps=5)
+    r = {"config": name, "stage": "receive chain (rate recovery + decode with parity-check stop + CRC)", "n_tb": n_tb, "C": C, "Z": Z,
+         "G": G, "ms": ms, "EsN0_dB": esn0, "tb_ok_fraction": float(okc.float().mean()), "mean_iters": float(iters.float().mean()),
+         "tb_per_s": n_tb / ms * 1e3, "payload_Gbit_s": n_tb * A / ms / 1e6}
+    print(r, flush=True)
+    out.append(r)
+    chain.close()
     return out
 
 

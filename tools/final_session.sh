@@ -1,17 +1,25 @@
 #!/bin/bash
-# The measurement set behind profiles/r02_*: GPU tests, host path, bench line, every BASELINE configuration, all lifting sizes,
-# chain stages (+ their kernel trace), Monte-Carlo loop, rocprofv3 kernel trace + PMC passes of the bench command.
+# The measurement set behind profiles/r03_*: GPU tests, bench line, every BASELINE configuration, all lifting sizes, chain stages
+# (+ their kernel trace), Monte-Carlo loop, host path, rocprofv3 kernel trace + PMC passes of the bench command.
+# TAG=r03 bash tools/final_session.sh ; then on the build box: python tools/collect_profiles.py r03
+TAG=${TAG:-r03}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-( time timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 ) > gpurun_out/gputests.log 2>&1; cat gpurun_out/gputests.log
-python tools/bench_host_path.py > gpurun_out/hostpath.log 2>&1
-python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/bench_line.json
+if [ -z "$SKIP_TESTS" ]; then
+( time timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 ) > gpurun_out/gputests.log 2>&1; cat gpurun_out/gputests.log
+fi
+python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_line_noprofile.json
 python tools/bench_configs.py > gpurun_out/cfg.log 2>&1
 python tools/bench_chain.py > gpurun_out/chain.log 2>&1
 python tools/bench_montecarlo.py > gpurun_out/mc.log 2>&1
-if [ -z "$SKIP_PROFILES" ]; then
-  python tools/bench_all_z.py > gpurun_out/allz.log 2>&1
-  bash tools/profile_gpu.sh r02 > gpurun_out/profile.log 2>&1
-fi
+python tools/bench_all_z.py > gpurun_out/allz.log 2>&1
+if [ -z "$SKIP_HOST" ]; then python tools/bench_host_path.py > gpurun_out/hostpath.log 2>&1; fi
+bash tools/profile_gpu.sh $TAG > gpurun_out/profile.log 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_chain -o chain -- python $GRAFT_REPO_ROOT/tools/bench_chain.py > $GRAFT_REPO_ROOT/gpurun_out/prof_chain.log 2>&1 )
-cut -c1-300 gpurun_out/bench_line.json
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg -o cfg -- python $GRAFT_REPO_ROOT/tools/bench_configs.py > $GRAFT_REPO_ROOT/gpurun_out/prof_cfg.log 2>&1 )
+# the bench line again, now that a profile of this very build exists on the box: summarise in place so that roofline.frac is filled
+python tools/summarise_profile.py $TAG > gpurun_out/summarise.log 2>&1
+python tools/isa_mix.py --form split --json profiles/${TAG}_headline_isa_mix.json > profiles/${TAG}_headline_isa_mix.txt 2>gpurun_out/isa_mix.err
+python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_line.json
+mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null
+cut -c1-400 gpurun_out/bench_line.json; tail -3 gpurun_out/summarise.log
