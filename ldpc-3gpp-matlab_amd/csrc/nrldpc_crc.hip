@@ -160,9 +160,89 @@ __global__ __launch_bounds__(256) void nrldpc_crc_attach_kernel(const CrcAttachA
     }
 }
 
+// ---- short transport blocks (C == 1, K' <= 512): one LANE per transport block --------------------------------------------
+// A wave per code block spends 64 lanes, an LDS staging round trip and a six-level combine tree on the reference's
+// demo-sized blocks (BASELINE configs[0]: 116 bits) and leaves the chip almost idle (0.02 of the HBM roofline at 65536
+// transport blocks).  Here a lane walks its own block bit by bit straight from global memory (4 bytes per load where the
+// rows are dword-aligned), 64 transport blocks per wave; same state machine as the wave kernels above.
+constexpr int CRC_LANE_MAX_BITS = 512;
+
+__device__ __forceinline__ uint32_t crc_step(uint32_t reg, uint32_t bit, uint32_t top, uint32_t mask, uint32_t poly) {
+    const uint32_t fb = ((reg & top) ? 1u : 0u) ^ (bit & 1u);
+    reg = (reg << 1) & mask;
+    return reg ^ (fb ? poly : 0u);
+}
+
+__global__ __launch_bounds__(256) void nrldpc_crc_check_lane_kernel(const CrcArgs a) {
+    const int tb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tb >= a.n_tb) return;
+    const uint8_t* row = a.c_hat + (size_t)tb * a.K;
+    uint8_t* b_hat = a.b_hat + (size_t)tb * a.B;
+    const int pay = a.Kp; // C == 1: no code-block CRC, the payload is B = K' bits (NRLDPCDecoder.m:298-309)
+    const uint32_t top = 1u << (a.tb.L - 1), mask = (1u << a.tb.L) - 1u, poly = a.tb.poly & mask;
+    const bool take = a.cbgti[0] != 0; // :304
+    const bool wide = ((a.K | a.B) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.c_hat) | reinterpret_cast<uintptr_t>(a.b_hat)) & 3) == 0;
+    uint32_t reg = 0;
+    if (take || a.keep_b_hat) {
+        const uint8_t* src = take ? row : b_hat; // :286-287: an untransmitted block keeps what an earlier step stored
+        if (wide) {
+            int i = 0;
+            for (; i + 4 <= pay; i += 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(src + i) & 0x01010101u;
+                reg = crc_step(reg, w, top, mask, poly);
+                reg = crc_step(reg, w >> 8, top, mask, poly);
+                reg = crc_step(reg, w >> 16, top, mask, poly);
+                reg = crc_step(reg, w >> 24, top, mask, poly);
+                if (take) *reinterpret_cast<uint32_t*>(b_hat + i) = w; // :303-309 payload copy
+            }
+            for (; i < pay; ++i) {
+                const uint8_t v = src[i] & 1u;
+                reg = crc_step(reg, v, top, mask, poly);
+                if (take) b_hat[i] = v;
+            }
+        } else {
+            for (int i = 0; i < pay; ++i) {
+                const uint8_t v = src[i] & 1u;
+                reg = crc_step(reg, v, top, mask, poly);
+                if (take) b_hat[i] = v;
+            }
+        }
+    } else { // :289: b_hat = zeros(B,1)
+        for (int i = 0; i < pay; ++i) b_hat[i] = 0;
+    }
+    int pass = take ? 1 : 0; // :305 (C == 1: the code-block CRC cannot fail)
+    if (a.cb_pass) {
+        int32_t* f = a.cb_pass + tb;
+        if (a.sticky) pass |= (*f != 0);
+        *f = pass;
+    }
+    a.ok[tb] = (reg != 0 || !pass) ? 0 : 1; // :337-339
+}
+
+__global__ __launch_bounds__(256) void nrldpc_crc_attach_lane_kernel(const CrcAttachArgs a) {
+    const int tb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tb >= a.n_tb) return;
+    const uint8_t* src = a.a + (size_t)tb * a.A;
+    uint8_t* c = a.c + (size_t)tb * a.K;
+    const int Ltb = a.B - a.A;
+    const uint32_t top = 1u << (a.tb.L - 1), mask = (1u << a.tb.L) - 1u, poly = a.tb.poly & mask;
+    uint32_t reg = 0;
+    for (int i = 0; i < a.A; ++i) { // NRLDPCEncoder.m:70-82
+        const uint8_t v = src[i] & 1u;
+        reg = crc_step(reg, v, top, mask, poly);
+        c[i] = v;
+    }
+    for (int i = 0; i < Ltb; ++i) c[a.A + i] = (uint8_t)((reg >> (Ltb - 1 - i)) & 1u);
+    for (int i = a.Kp; i < a.K; ++i) c[i] = 0; // fillers (:120-122,153)
+}
+
 static int waves_for(int C) { return C < 4 ? C : 4; }
 
 hipError_t launch_crc_attach(const CrcAttachArgs& a, hipStream_t stream) {
+    if (a.C == 1 && a.Kp <= CRC_LANE_MAX_BITS && a.n_tb >= 4096) { // short blocks, enough of them to fill the chip lane-wise
+        hipLaunchKernelGGL(nrldpc_crc_attach_lane_kernel, dim3((a.n_tb + 255) / 256), dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
     const int nw = waves_for(a.C);
     const size_t lds = (size_t)nw * row_capacity(a.K) + 4 * (size_t)a.C + 16;
     hipLaunchKernelGGL(nrldpc_crc_attach_kernel, dim3(a.n_tb), dim3(64 * nw), lds, stream, a);
@@ -170,6 +250,10 @@ hipError_t launch_crc_attach(const CrcAttachArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_crc_check(const CrcArgs& a, hipStream_t stream) {
+    if (a.C == 1 && a.Kp <= CRC_LANE_MAX_BITS && a.n_tb >= 4096) {
+        hipLaunchKernelGGL(nrldpc_crc_check_lane_kernel, dim3((a.n_tb + 255) / 256), dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
     const int nw = waves_for(a.C);
     const size_t lds = (size_t)nw * row_capacity(a.K) + 8 * (size_t)a.C + 16;
     hipLaunchKernelGGL(nrldpc_crc_check_kernel, dim3(a.n_tb), dim3(64 * nw), lds, stream, a);

@@ -238,8 +238,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
         });
         constexpr int npart = pcount_before<PART>(ncore);
         if constexpr (PART == (NRLDPC_Z64_DEFER_EXT ? 1 : 0) && HAS_EXT) { // the extension bit is thread-private: never "late"
-            if constexpr (XF) lam = st.xf[XI];
-            else lam = byte_to_f32<XI & 3>(st.xq[XI >> 2]);
+            lam = st.template ext<XI, XF>();
             const float al = fabsf(lam);
             pm2 = __builtin_amdgcn_fmed3f(al, pm1, pm2);
             pm1 = fminf(pm1, al);

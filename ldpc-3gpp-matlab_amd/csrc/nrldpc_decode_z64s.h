@@ -32,16 +32,15 @@ namespace nrldpc {
 #ifndef NRLDPC_Z64S_PRIO
 #define NRLDPC_Z64S_PRIO 2
 #endif
-#ifndef NRLDPC_Z64S_XF
-#define NRLDPC_Z64S_XF 0 // extension LLRs as floats (1) or packed int8 (0)
-#endif
 
 template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
     using B = Z64<BG, ZC, 1, NL>;
     static constexpr int NG = LayerGroups<BG, NL>::ngroups();
     static constexpr int THREADS = 2 * B::TPC;
     static constexpr bool usable() { return THREADS <= 1024 && NG >= 2; }
-    static constexpr size_t lds_bytes() { return (size_t)B::CWS + B::GUARD + 16; }
+    // rings + trailing guard + flags + the extension-column channel LLRs (one int8 per extension row and row-thread)
+    static constexpr size_t XOFF = (size_t)B::CWS + B::GUARD + 16;
+    static constexpr size_t lds_bytes() { return XOFF + (size_t)(NL - 4) * ZC; }
 };
 
 template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
@@ -104,7 +103,13 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef NRLDPC_Z64S_MIRROR_BIT
+    // experiment: workgroups whose index has this bit set swap the halves' wave ranges, so that the two workgroups of a CU
+    // put complementary (2 + 1 / 1 + 2) mixes of finishing and preparing waves on each SIMD
+    const int half = (wave / G::NWV) ^ ((blockIdx.x >> NRLDPC_Z64S_MIRROR_BIT) & 1), w = wave % G::NWV, lane = tid & 63;
+#else
     const int half = wave / G::NWV, w = wave % G::NWV, lane = tid & 63;
+#endif
     if constexpr (G::BLK < 64) {
         if (lane >= G::BLK) return; // these lanes own no row; barriers count waves, not lanes
     }
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     const int cw = blockIdx.x;
     int* flags = reinterpret_cast<int*>(lds + (size_t)G::CWS + G::GUARD);
     constexpr size_t ncwz = (size_t)G::COLS * ZC;
-    constexpr bool XF = NRLDPC_Z64S_XF != 0;
+    constexpr bool XF = false; // extension LLRs: int8 in LDS (DecStateS)
 
     uint32_t R[G::NWV];
 #pragma unroll
@@ -200,11 +205,11 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     auto run = [&](auto hc) {
         constexpr int H = decltype(hc)::value;
         using O = Own<BG, NL, H>;
-        DecStateS<BG, NL, H> st;
+        DecStateS<BG, NL, H, ZC> st;
 #pragma unroll
         for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
-#pragma unroll
-        for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
+        // half 0's extension rows first, then half 1's: [row][thread] bytes
+        st.xp = (lds_i8_t)(lds + G::XOFF + (size_t)(H == 0 ? 0 : Own<BG, NL, 0>::NEXT) * ZC + z);
         // extension LLRs of this half's rows: thread-private, one load per row; raw bits first, conversions after, in a
         // body per LLR format (no format test per load: see the prologue of the one-thread-per-row kernel)
         auto load_ext = [&](auto kind_c) {
@@ -224,17 +229,11 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                 float v;
                 if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)xe[i]));
                 else v = __uint_as_float(xe[i]);
-                f32_to_byte<i & 3>(st.xq[i >> 2], ingest(v, a.scale, false));
+                st.xp[i * ZC] = (int8_t)(int)ingest(v, a.scale, false); // thread-private: no barrier needed before its reads
             });
         };
         if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});
         else load_ext(std::integral_constant<int, NRLDPC_K_F32>{});
-        if constexpr (XF) {
-            static_for<O::NEXT>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                st.xf[i] = byte_to_f32<i & 3>(st.xq[i >> 2]);
-            });
-        }
         __syncthreads(); // the a-posteriori rings are complete
         const float cap = (127.49f + a.beta) / a.alpha; // see LayerZ64::track3
         DecArgs av = a;                                  // alpha, 2^23 - beta as VGPR values: see the one-thread-per-row kernel
@@ -269,7 +268,10 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                     constexpr int L = PO.v[i];
                     if (!stop) {
                         bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
-                        if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n) stop = __any((int)bad) != 0;
+                        // (a vote right after every dense row as well: a vote is a point the compiler cannot move loads across,
+                        // and 19 + 16 a-posteriori words in flight spill at 80 VGPRs)
+                        if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n || O::ncore(L) > 10 || (i + 1 < PO.n && O::ncore(PO.v[i + 1 < PO.n ? i + 1 : i]) > 10))
+                            stop = __any((int)bad) != 0;
                     }
                 });
                 if (bad) flags[0] = 1;
@@ -282,11 +284,18 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     if (half == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
 
-    if (a.iters && u == 0) a.iters[cw] = my_iters;
+    // Write-back.  Every index is derived AGAIN from the thread id, through an opaque copy: values computed before the iteration
+    // loop and needed only here would otherwise stay live across it, and at 80 VGPRs the compiler parks them in scratch
+    // (8 dwords per thread written to and read from HBM: measured as 1.5x the compulsory traffic).
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int wave2 = tid2 >> 6;
+    const int half2 = wave2 / G::NWV, z2 = (wave2 % G::NWV) * G::BLK + (tid2 & 63), u2 = half2 * ZC + z2;
+    if (a.iters && u2 == 0) a.iters[cw] = my_iters;
     uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * ZC);
     if ((reinterpret_cast<uintptr_t>(a.hard) & 3) == 0) {
         constexpr int QW = ZC / 4;
-        const int qs = u / QW, qq = u - qs * QW;
+        const int qs = u2 / QW, qq = u2 - qs * QW;
         static_for<(G::KB + 7) / 8>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const int c = 8 * k + qs;
@@ -300,9 +309,9 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     } else {
         static_for<(G::KB + 1) / 2>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const int c = 2 * k + half;
+            const int c = 2 * k + half2;
             if (2 * k + 1 < G::KB || c < G::KB)
-                hard[(size_t)c * ZC + z] = *reinterpret_cast<const float*>(lds + G::GUARD + 4 * z + c * G::CS) < 0.0f ? 1 : 0;
+                hard[(size_t)c * ZC + z2] = *reinterpret_cast<const float*>(lds + G::GUARD + 4 * z2 + c * G::CS) < 0.0f ? 1 : 0;
         });
     }
 }

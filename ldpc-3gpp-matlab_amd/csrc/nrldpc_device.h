@@ -210,16 +210,29 @@ __device__ __forceinline__ float scale_mag(const DecArgs& a, float m) {
 template <int BG> struct DecState {
     uint32_t rm[BGD<BG>::NW];  // check-to-variable messages, int8 x4
     uint32_t xq[BGD<BG>::NXW]; // extension-column channel LLRs, int8 x4
+    // channel LLR of this thread's XI-th extension bit (XF: from the float copy)
+    template <int XI, bool XF> __device__ __forceinline__ float ext() const {
+        if constexpr (XF) return xf[XI];
+        else return byte_to_f32<XI & 3>(xq[XI >> 2]);
+    }
     // the same LLRs as floats, for the builds whose register budget has room for them (one v_cvt_f32_i32_sdwa per
     // extension row and iteration saved); never touched -- so never allocated -- by the others
     float xf[BGD<BG>::NEXT];
 };
 
-// per-thread state of a split kernel's half H (see Own)
-template <int BG, int NL, int H> struct DecStateS {
+// per-thread state of a split kernel's half H (see Own).  The extension-column channel LLRs live in LDS, one int8 per
+// row and thread ([row][thread]: a wave reads 64 consecutive bytes, conflict-free) -- they are read once per row and
+// iteration (ds_read_i8 + v_cvt_f32_i32, the cost of the SDWA unpack they replace), and the 6 registers they would take
+// are what the 80-VGPR budget of 6 waves per SIMD is short of: with them in registers the compiler spilled message words
+// to scratch, and the scratch traffic showed up as 1.5x the compulsory HBM bytes.
+typedef int8_t __attribute__((address_space(3))) * lds_i8_t;
+template <int BG, int NL, int H, int XS> struct DecStateS {
     uint32_t rm[Own<BG, NL, H>::NW];
-    uint32_t xq[Own<BG, NL, H>::NXW];
-    float xf[Own<BG, NL, H>::NEXT > 0 ? Own<BG, NL, H>::NEXT : 1];
+    lds_i8_t xp; // this thread's byte of its half's extension row 0; row XI is XI * XS bytes further (an immediate offset)
+    template <int XI, bool XF> __device__ __forceinline__ float ext() const {
+        static_assert(!XF, "the split kernels keep extension LLRs in LDS");
+        return (float)(int)xp[XI * XS];
+    }
 };
 
 // The same for the software-pipelined builds, with nbeta23 = 2^23 - beta held in a VGPR: v_fma + v_max + v_sub

@@ -205,3 +205,50 @@ def test_channel_kernel_matches_numpy_restatement(pkg, Q_m, esn0):
     with pytest.raises(pkg.NRLDPCError):
         pkg.awgn_llr_dev(d_g.data_ptr(), 7, 2, 0.0, 1, 0, out.data_ptr())
 
+
+@pytest.mark.parametrize("kw", [dict(BG=2, A=100, G=300, Q_m=2), dict(BG=2, A=12, G=60, Q_m=2), dict(BG=1, A=300, G=900, Q_m=2),
+                                dict(BG=2, A=101, G=300, Q_m=2)])
+def test_short_block_crc_kernels_equal_the_wave_kernels(pkg, orc, kw):
+    """Short transport blocks in large batches (C = 1, K' <= 512, n_tb >= 4096 -- BASELINE configs[0] at Monte-Carlo batch
+    sizes) take the one-lane-per-transport-block CRC kernels; the same data in batches below 4096 takes the
+    one-wave-per-code-block kernels.  Both must agree byte for byte (and the attach side with the host mirror, itself
+    checked against the bit-serial oracle), through the reference's state machine: plain check, HARQ keep with an
+    untransmitted block (CBGTI), sticky flags."""
+    import torch
+    enc = pkg.NRLDPCEncoder(**kw)
+    enc.validate()
+    assert enc.C == 1 and int(enc.K_prime) <= 512
+    rng = np.random.default_rng(enc.A)
+    n_tb = 5003
+    a = rng.integers(0, 2, (n_tb, enc.A), dtype=np.uint8)
+    d_a = torch.from_numpy(a).cuda()
+    c_lane = torch.full((n_tb, enc.K), 9, dtype=torch.uint8, device="cuda")
+    pkg.crc_attach_dev(enc, d_a.data_ptr(), n_tb, c_lane.data_ptr())
+    torch.cuda.synchronize()
+    want = enc.code_block_segmentation(enc.crc_calculation(a)).reshape(n_tb, enc.K)
+    assert (c_lane.cpu().numpy() == want).all()
+    assert orc.crc(enc.transport_block_CRC_polynomial, enc.transport_block_L, want[7, :int(enc.K_prime)]) == 0
+    c_hat = want.copy()
+    bad = rng.random(n_tb) < 0.3
+    c_hat[bad, rng.integers(0, int(enc.K_prime))] ^= 1
+    c_hat[:, int(enc.K_prime):] = rng.integers(0, 2, (n_tb, enc.K - int(enc.K_prime)), dtype=np.uint8)
+    d_c = torch.from_numpy(c_hat).cuda()
+
+    def run(chunk, cbgti, keep, b0, f0):
+        b = torch.from_numpy(b0.copy()).cuda(); f = torch.from_numpy(f0.copy()).cuda()
+        ok = torch.zeros(n_tb, dtype=torch.int32, device="cuda")
+        for lo in range(0, n_tb, chunk):
+            n = min(chunk, n_tb - lo)
+            pkg.crc_check_harq_dev(enc, d_c.data_ptr() + lo * enc.K, n, b.data_ptr() + lo * enc.B, ok.data_ptr() + 4 * lo,
+                                   f.data_ptr() + 4 * lo, cbgti, keep)
+        torch.cuda.synchronize()
+        return b.cpu().numpy(), f.cpu().numpy(), ok.cpu().numpy()
+    b0 = rng.integers(0, 2, (n_tb, enc.B), dtype=np.uint8)           # what "an earlier step stored"
+    f0 = (rng.random((n_tb, 1)) < 0.5).astype(np.int32)
+    for cbgti, keep in ((None, False), (None, True), ([0], True), ([0], False)):
+        lane = run(n_tb, cbgti, keep, b0, f0)                         # one launch of 5003: lane kernels
+        wave = run(1000, cbgti, keep, b0, f0)                         # launches of <= 1000: wave kernels
+        for x, y in zip(lane, wave):
+            assert (x == y).all(), (kw, cbgti, keep)
+        if cbgti is None:
+            assert (lane[2] == 1).sum() > 0 and ((lane[2] == 0) == bad).all()
