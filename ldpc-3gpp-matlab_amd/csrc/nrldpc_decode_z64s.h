@@ -103,13 +103,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef NRLDPC_Z64S_MIRROR_BIT
-    // experiment: workgroups whose index has this bit set swap the halves' wave ranges, so that the two workgroups of a CU
-    // put complementary (2 + 1 / 1 + 2) mixes of finishing and preparing waves on each SIMD
-    const int half = (wave / G::NWV) ^ ((blockIdx.x >> NRLDPC_Z64S_MIRROR_BIT) & 1), w = wave % G::NWV, lane = tid & 63;
-#else
     const int half = wave / G::NWV, w = wave % G::NWV, lane = tid & 63;
-#endif
     if constexpr (G::BLK < 64) {
         if (lane >= G::BLK) return; // these lanes own no row; barriers count waves, not lanes
     }

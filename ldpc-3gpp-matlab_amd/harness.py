@@ -119,29 +119,36 @@ _SM64 = (0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB)
 
 def payload_bits_np(seed, first_block, n, A):
     """Payload of transport blocks first_block .. first_block+n-1 (numpy restatement of payload_bits): bit i of block b is
-    the top bit of splitmix64(seed + (b*A + i) * golden) -- a function of the GLOBAL block index only, so any split of a
-    batch over devices draws the same payloads (the reference draws round(rand(A,1)) per block, plot_BLER_vs_SNR.m:118)."""
-    idx = (np.arange(first_block, first_block + n, dtype=np.uint64)[:, None] * np.uint64(A) + np.arange(A, dtype=np.uint64)[None, :])
+    bit (i mod 64) of splitmix64(seed + (b*W + i div 64 + 1) * golden), W = ceil(A/64) -- a function of the GLOBAL block
+    index only, so any split of a batch over devices draws the same payloads (the reference draws round(rand(A,1)) per
+    block, plot_BLER_vs_SNR.m:118)."""
+    W = (A + 63) // 64
+    idx = (np.arange(first_block, first_block + n, dtype=np.uint64)[:, None] * np.uint64(W) + np.arange(W, dtype=np.uint64)[None, :])
     with np.errstate(over="ignore"):
         x = np.uint64(seed % (1 << 64)) + (idx + np.uint64(1)) * np.uint64(_SM64[0])
         x = (x ^ (x >> np.uint64(30))) * np.uint64(_SM64[1])
         x = (x ^ (x >> np.uint64(27))) * np.uint64(_SM64[2])
         x = x ^ (x >> np.uint64(31))
-    return (x >> np.uint64(63)).astype(np.uint8)
+    bits = (x[:, :, None] >> np.arange(64, dtype=np.uint64)[None, None, :]) & np.uint64(1)
+    return bits.reshape(n, W * 64)[:, :A].astype(np.uint8)
 
 
 def payload_bits(seed, first_block, n, A, dev):
-    """The same on the device (int64 arithmetic wraps like uint64; right shifts made logical by masking)."""
+    """The same on the device: one hash per 64 payload bits (int64 arithmetic wraps like uint64; right shifts made logical
+    by masking), bits unpacked from the little-endian byte view."""
     import torch
     s64 = lambda c: c - (1 << 64) if c >= (1 << 63) else c
     lsr = lambda x, k: (x >> k) & ((1 << (64 - k)) - 1)
-    idx = (torch.arange(first_block, first_block + n, device=dev, dtype=torch.int64)[:, None] * A
-           + torch.arange(A, device=dev, dtype=torch.int64)[None, :])
+    W = (A + 63) // 64
+    idx = (torch.arange(first_block, first_block + n, device=dev, dtype=torch.int64)[:, None] * W
+           + torch.arange(W, device=dev, dtype=torch.int64)[None, :])
     x = (idx + 1) * s64(_SM64[0]) + s64(seed % (1 << 64))
     x = (x ^ lsr(x, 30)) * s64(_SM64[1])
     x = (x ^ lsr(x, 27)) * s64(_SM64[2])
     x = x ^ lsr(x, 31)
-    return lsr(x, 63).to(torch.uint8)
+    by = x.contiguous().view(torch.uint8).reshape(n, W * 8, 1)                     # little-endian bytes of every word
+    bits = (by >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1
+    return bits.reshape(n, W * 64)[:, :A].contiguous()
 
 
 ATTEMPT_STRIDE = 1 << 40  # Philox symbol counter = attempt * 2^40 + global block index * symbols per block + symbol
