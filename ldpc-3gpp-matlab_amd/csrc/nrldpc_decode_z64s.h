@@ -38,9 +38,18 @@ template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
     static constexpr int NG = LayerGroups<BG, NL>::ngroups();
     static constexpr int THREADS = 2 * B::TPC;
     static constexpr bool usable() { return THREADS <= 1024 && NG >= 2; }
-    // rings + trailing guard + flags + the extension-column channel LLRs (one int8 per extension row and row-thread)
+    // rings + trailing guard + flags [+ the extension-column channel LLRs, one int8 per extension row and row-thread]
     static constexpr size_t XOFF = (size_t)B::CWS + B::GUARD + 16;
-    static constexpr size_t lds_bytes() { return XOFF + (size_t)(NL - 4) * ZC; }
+    static constexpr size_t XBYTES = (size_t)(NL - 4) * ZC;
+    // Workgroups a CU holds: 24 wave slots at the 80-VGPR budget, 160 KB of LDS.  The extension LLRs move from 6 registers
+    // per thread into LDS exactly where that does not cost a workgroup (Z = 384, 288, 256, 240 ... : the wave slots bind;
+    // Z <= 192 with 2- to 6-wave workgroups: LDS binds, and one workgroup fewer per CU costs 4-8 %, measured).
+    static constexpr int wgs_per_cu(size_t lds) {
+        const int by_waves = 24 / (2 * B::NWV) > 0 ? 24 / (2 * B::NWV) : 1, by_lds = (int)((160 * 1024) / lds);
+        return by_waves < by_lds ? by_waves : by_lds;
+    }
+    static constexpr bool XL = wgs_per_cu(XOFF + XBYTES) == wgs_per_cu(XOFF);
+    static constexpr size_t lds_bytes() { return XOFF + (XL ? XBYTES : 0); }
 };
 
 template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     const int cw = blockIdx.x;
     int* flags = reinterpret_cast<int*>(lds + (size_t)G::CWS + G::GUARD);
     constexpr size_t ncwz = (size_t)G::COLS * ZC;
-    constexpr bool XF = false; // extension LLRs: int8 in LDS (DecStateS)
+    constexpr bool XF = false; // extension LLRs: int8 in LDS or in registers (DecStateS, Z64S::XL), never floats
 
     uint32_t R[G::NWV];
 #pragma unroll
@@ -199,11 +208,15 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     auto run = [&](auto hc) {
         constexpr int H = decltype(hc)::value;
         using O = Own<BG, NL, H>;
-        DecStateS<BG, NL, H, ZC> st;
+        DecStateS<BG, NL, H, ZC, G::XL> st;
 #pragma unroll
         for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
-        // half 0's extension rows first, then half 1's: [row][thread] bytes
-        st.xp = (lds_i8_t)(lds + G::XOFF + (size_t)(H == 0 ? 0 : Own<BG, NL, 0>::NEXT) * ZC + z);
+        if constexpr (G::XL) { // half 0's extension rows first, then half 1's: [row][thread] bytes
+            st.xp = (lds_i8_t)(lds + G::XOFF + (size_t)(H == 0 ? 0 : Own<BG, NL, 0>::NEXT) * ZC + z);
+        } else {
+#pragma unroll
+            for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
+        }
         // extension LLRs of this half's rows: thread-private, one load per row; raw bits first, conversions after, in a
         // body per LLR format (no format test per load: see the prologue of the one-thread-per-row kernel)
         auto load_ext = [&](auto kind_c) {
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
                 float v;
                 if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)xe[i]));
                 else v = __uint_as_float(xe[i]);
-                st.xp[i * ZC] = (int8_t)(int)ingest(v, a.scale, false); // thread-private: no barrier needed before its reads
+                st.template set_ext<i>(ingest(v, a.scale, false)); // thread-private: no barrier needed before its reads
             });
         };
         if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});

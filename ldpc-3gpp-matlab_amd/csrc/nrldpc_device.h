@@ -226,13 +226,24 @@ template <int BG> struct DecState {
 // are what the 80-VGPR budget of 6 waves per SIMD is short of: with them in registers the compiler spilled message words
 // to scratch, and the scratch traffic showed up as 1.5x the compulsory HBM bytes.
 typedef int8_t __attribute__((address_space(3))) * lds_i8_t;
-template <int BG, int NL, int H, int XS> struct DecStateS {
+template <int BG, int NL, int H, int XS, bool XL> struct DecStateS;
+template <int BG, int NL, int H, int XS> struct DecStateS<BG, NL, H, XS, true> { // extension LLRs in LDS
     uint32_t rm[Own<BG, NL, H>::NW];
     lds_i8_t xp; // this thread's byte of its half's extension row 0; row XI is XI * XS bytes further (an immediate offset)
     template <int XI, bool XF> __device__ __forceinline__ float ext() const {
-        static_assert(!XF, "the split kernels keep extension LLRs in LDS");
+        static_assert(!XF, "the split kernels keep no float copy of the extension LLRs");
         return (float)(int)xp[XI * XS];
     }
+    template <int XI> __device__ __forceinline__ void set_ext(float q) { xp[XI * XS] = (int8_t)(int)q; }
+};
+template <int BG, int NL, int H, int XS> struct DecStateS<BG, NL, H, XS, false> { // extension LLRs in registers, int8 x4
+    uint32_t rm[Own<BG, NL, H>::NW];
+    uint32_t xq[Own<BG, NL, H>::NXW > 0 ? Own<BG, NL, H>::NXW : 1];
+    template <int XI, bool XF> __device__ __forceinline__ float ext() const {
+        static_assert(!XF, "the split kernels keep no float copy of the extension LLRs");
+        return byte_to_f32<XI & 3>(xq[XI >> 2]);
+    }
+    template <int XI> __device__ __forceinline__ void set_ext(float q) { f32_to_byte<XI & 3>(xq[XI >> 2], q); }
 };
 
 // The same for the software-pipelined builds, with nbeta23 = 2^23 - beta held in a VGPR: v_fma + v_max + v_sub

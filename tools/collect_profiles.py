@@ -10,6 +10,13 @@ pairs = [("bench_line.json", "_bench_line.json"), ("bench_configs.json", "_bench
          ("bench_host_path.json", "_bench_host_path.json"), ("bler_gap.json", "_bler_gap.json"),
          ("prof_chain/chain_kernel_stats.csv", "_chain_kernel_stats.csv"), ("prof_cfg/cfg_kernel_stats.csv", "_configs_kernel_stats.csv"),
          ("gputests.log", "_gputests.txt")]
+# what the box summarised in place (PMC summary, traffic, kernel stats, instruction mix) first; the session's own outputs then
+# overwrite any stale copy of themselves that travelled to the box inside profiles/
+d = os.path.join(G, "profiles_" + tag)
+if os.path.isdir(d):
+    for f in sorted(os.listdir(d)):
+        shutil.copy(os.path.join(d, f), os.path.join(P, f))
+        print("copied", f)
 for src, dst in pairs:
     s = os.path.join(G, src)
     if os.path.exists(s):
@@ -17,11 +24,6 @@ for src, dst in pairs:
         print("copied", src, "->", tag + dst)
     else:
         print("missing", src)
-d = os.path.join(G, "profiles_" + tag)
-if os.path.isdir(d):
-    for f in sorted(os.listdir(d)):
-        shutil.copy(os.path.join(d, f), os.path.join(P, f))
-        print("copied", f)
 # the kernel-trace tables carry the build they belong to (a trace older than the kernels beside it)
 ids = {}
 try:
