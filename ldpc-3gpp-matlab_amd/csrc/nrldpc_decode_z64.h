@@ -158,6 +158,23 @@ template <int LO, int HI, class F> __device__ __forceinline__ void dispatch_w(in
     }
 }
 
+// Split kernels (nrldpc_decode_z64s.h): are the dense core rows 0..3 worked on by both halves at once (Own::dual)?  BG1 only
+// (19 edges per row; BG2's rows 0..3 have 8-10), and only where the halves' exchange buffer (16 Z bytes of LDS) does not cost
+// a workgroup per CU.  Measured at BG1 Z = 384: all rows -1.8 % (fixed 25) / -2 % (parity stop); 5 / 13 / 24 rows -2 / -5 / -3 %
+// (fixed), -5 / -2 / -2 % (parity stop).  -DNRLDPC_Z64S_DUAL=0/1 forces it (A/B).
+template <int BG, int ZC, int NL> constexpr bool z64s_dual() {
+#ifdef NRLDPC_Z64S_DUAL
+    return NRLDPC_Z64S_DUAL != 0 && BG == 1;
+#endif
+    if (BG != 1) return false;
+    using B = Z64<BG, ZC, 1, NL>;
+    constexpr size_t base = (size_t)B::CWS + B::GUARD + 16;
+    constexpr int by_waves = 24 / (2 * B::NWV) > 0 ? 24 / (2 * B::NWV) : 1;
+    constexpr int w0 = (int)((160 * 1024) / base) < by_waves ? (int)((160 * 1024) / base) : by_waves;
+    constexpr int w1 = (int)((160 * 1024) / (base + 16 * ZC)) < by_waves ? (int)((160 * 1024) / (base + 16 * ZC)) : by_waves;
+    return w1 == w0;
+}
+
 // One base-graph layer for this thread's check row, split into phases so that the layers of a
 // column-disjoint barrier group can issue all their LDS reads first and share one mirror dispatch.
 template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> struct LayerZ64 {
@@ -166,8 +183,16 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
     static constexpr int deg = G::row_ptr(L + 1) - e0;
     static constexpr bool HAS_EXT = (L >= 4);
     static constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
-    static constexpr int ce0 = Own<BG, NL, H>::core_base(L); // first message byte of this layer in the thread's store
-    static constexpr int XI = HAS_EXT ? Own<BG, NL, H>::ext_index(L) : 0; // its extension LLR there
+    using OW = Own<BG, NL, H, (H >= 0 && z64s_dual<BG, ZC, NL>())>;
+    static constexpr int ce0 = OW::core_base(L); // first message byte of this layer in the thread's store
+    static constexpr int XI = HAS_EXT ? OW::ext_index(L) : 0; // its extension LLR there
+    static constexpr bool DUALROW = OW::dual(L);  // the row's edges alternate between the two halves
+    static constexpr bool owned(int j) { return !DUALROW || (j % 2 == H); }
+    static constexpr int cidx(int j) {                                    // message byte of edge j in the thread's store
+        int n = ce0;
+        for (int i = 0; i < j; ++i) n += owned(i) ? 1 : 0;
+        return n;
+    }
     float t[ncore];
     float lam, m1, M1, M2;
 
@@ -193,7 +218,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
     template <bool LATE> __device__ __forceinline__ void load_part(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if constexpr (LayerZ64::is_late(j) == LATE) {
+            if constexpr (LayerZ64::is_late(j) == LATE && LayerZ64::owned(j)) {
                 constexpr int P = G::shift(e0 + j);
                 t[j] = *reinterpret_cast<const float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK));
             }
@@ -213,7 +238,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
     // integers, so results do not depend on the split.
     static constexpr bool is_deferred(int j) { return !is_late(j) && part_count_before<false>(j) < NRLDPC_Z64_DEFER; }
     // PART 0: early, tracked before the barrier (starts the search); 1: early, deferred; 2: late
-    static constexpr int part_of(int j) { return is_late(j) ? 2 : is_deferred(j) ? 1 : 0; }
+    static constexpr int part_of(int j) { return !owned(j) ? 3 : is_late(j) ? 2 : is_deferred(j) ? 1 : 0; }
     template <int PART> static constexpr int pcount_before(int j) {
         int n = 0;
         for (int i = 0; i < j; ++i) n += (part_of(i) == PART);
@@ -226,7 +251,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (LayerZ64::part_of(j) == PART) {
-                constexpr int ce = ce0 + j;
+                constexpr int ce = LayerZ64::cidx(j);
                 const float tj = t[j] - byte_to_f32<ce & 3>(st.rm[ce >> 2]);
                 t[j] = tj;
                 const float aj = fabsf(tj);
@@ -256,7 +281,19 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
             track3<0, XF>(st, cap);
         }
     }
-    // pass 2 for all edges after both parts have been tracked
+    // Dual rows: this half's partial search result -> LDS (m1, m2 with the sign parity in m2's sign bit: both are >= 0) ...
+    __device__ __forceinline__ void publish(char* lds, uint32_t xmine) const {
+        *reinterpret_cast<float2*>(lds + xmine) = make_float2(pm1, __uint_as_float(fbits(pm2) | (pS & 0x80000000u)));
+    }
+    // ... and the other half's merged in: two smallest of {pm1 <= pm2, o1 <= o2}, parities xor-ed
+    __device__ __forceinline__ void merge(const char* lds, uint32_t xother) {
+        const float2 o = *reinterpret_cast<const float2*>(lds + xother);
+        const float o2 = fabsf(o.y);
+        pS ^= fbits(o.y);
+        pm2 = fminf(fminf(fmaxf(pm1, o.x), pm2), o2);
+        pm1 = fminf(pm1, o.x);
+    }
+    // pass 2 for all (owned) edges after every part has been tracked
     template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
         m1 = pm1;
         // magnitudes carrying the row's sign parity: M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
@@ -266,19 +303,21 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
         bool ismin[ncore]; // all compares first: keeps v_cmp -> v_cndmask hazard slots filled with useful work
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            ismin[j] = fabsf(t[j]) == m1;
+            if constexpr (LayerZ64::owned(j)) ismin[j] = fabsf(t[j]) == m1;
         });
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            constexpr int ce = ce0 + j;
-            constexpr int P = G::shift(e0 + j);
-            const float tj = t[j];
-            const float mag = ismin[j] ? M2 : M1;
-            const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
-            f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
-            const float v = tj + r;
-            t[j] = v;
-            *reinterpret_cast<float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK)) = v;
+            if constexpr (LayerZ64::owned(j)) {
+                constexpr int ce = LayerZ64::cidx(j);
+                constexpr int P = G::shift(e0 + j);
+                const float tj = t[j];
+                const float mag = ismin[j] ? M2 : M1;
+                const float r = __uint_as_float(fbits(mag) ^ (fbits(tj) & 0x80000000u));
+                f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
+                const float v = tj + r;
+                t[j] = v;
+                *reinterpret_cast<float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK)) = v;
+            }
         });
     }
 
@@ -337,8 +376,8 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
             constexpr int P = G::shift(e0 + j);
             constexpr int ka = P / G::BLK;
             constexpr int off = G::col(e0 + j) * G::CS + 4 * (P % G::BLK);
-            if constexpr ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
-                          (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV)) {
+            if constexpr (LayerZ64::owned(j) && ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
+                                                 (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV))) {
                 if constexpr (G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV)
                     *reinterpret_cast<float*>(lds + RA + off) = t[j];
                 if constexpr (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV)

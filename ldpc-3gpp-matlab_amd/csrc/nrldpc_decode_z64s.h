@@ -48,8 +48,12 @@ template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
         const int by_waves = 24 / (2 * B::NWV) > 0 ? 24 / (2 * B::NWV) : 1, by_lds = (int)((160 * 1024) / lds);
         return by_waves < by_lds ? by_waves : by_lds;
     }
-    static constexpr bool XL = wgs_per_cu(XOFF + XBYTES) == wgs_per_cu(XOFF);
-    static constexpr size_t lds_bytes() { return XOFF + (XL ? XBYTES : 0); }
+    // dual rows (Own::dual): the exchange buffer of the two halves' partial searches, 8 bytes per thread
+    static constexpr bool DUAL = Own<BG, NL, 0, z64s_dual<BG, ZC, NL>()>::dual(0);
+    static constexpr size_t XCHBYTES = DUAL ? (size_t)2 * ZC * 8 : 0;
+    static constexpr bool XL = wgs_per_cu(XOFF + XCHBYTES + XBYTES) == wgs_per_cu(XOFF + XCHBYTES);
+    static constexpr size_t XCHOFF = (XOFF + (XL ? XBYTES : 0) + 7) & ~(size_t)7;
+    static constexpr size_t lds_bytes() { return XCHOFF + XCHBYTES; }
 };
 
 template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
@@ -78,7 +82,7 @@ __device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ6
     }
     if constexpr (GI + 1 < NG) {
         s_early<BG, ZC, NL, H, ET, XF, GI + 1>(next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
-    } else if constexpr (H == 0) {
+    } else if constexpr (H == 0 || Own<BG, NL, H, z64s_dual<BG, ZC, NL>()>::dual(0)) { // (a dual row 0: both halves prepare their own edges of it)
         // odd group count: this half owns the last group AND group 0, whose early part it runs right here (the one
         // interval per iteration that is software-pipelined within a wave, as in pipeline_z64)
         next0.template loads<false>(lds, R);
@@ -98,7 +102,47 @@ __device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& s
         nxt.template loads<false>(lds, R); // columns group GI does not write
         nxt.template track<false, XF>(st, cap);
         s_crit<BG, ZC, NL, H, ET, XF, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
-    } else if constexpr (H == 0) { // even group count: the last group is the other half's, group 0 is this one's
+    } else if constexpr (H == 0 || Own<BG, NL, H, z64s_dual<BG, ZC, NL>()>::dual(0)) { // even group count: the last group is the other half's, group 0 is this one's
+        next0.template loads<false>(lds, R);
+        next0.template track<false, XF>(st, cap);
+    }
+}
+
+// interval(s) of a dual row GI (a one-layer group worked on by both halves, Own::dual): `cur` arrives with this half's early
+// edges done.  Two barriers: the usual one in front of the group, and one between the halves' partial searches and pass 2.
+template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
+__device__ __forceinline__ void s_dense(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds,
+                                        const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
+                                        float cap, uint32_t& esign_lo, uint32_t& esign_hi, uint32_t xmine, uint32_t xother) {
+    using O = Own<BG, NL, H, z64s_dual<BG, ZC, NL>()>;
+    using LG = LayerGroups<BG, NL>;
+    constexpr int NG = LG::ngroups();
+    static_assert(LG::group_last(LG::group_first(GI)) == LG::group_first(GI), "a dual row is a barrier group of its own");
+    if constexpr (!(ET && GI == 0)) __syncthreads(); // see s_crit
+    __builtin_amdgcn_s_setprio(NRLDPC_Z64S_PRIO);
+    cur.template loads<true>(lds, R);
+    cur.template track<true, XF>(st, cap);
+    cur.l0.publish(lds, xmine);
+    __syncthreads();
+    cur.l0.merge(lds, xother);
+    cur.finish(st, lds, R, a);
+    cur.twins(lds, RA, RB, w);
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (GI + 1 < NG) {
+        if constexpr (O::dual(LG::group_first(GI + 1))) {
+            GroupZ64<BG, ZC, GI + 1, NL, H> nxt;
+            nxt.template loads<false>(lds, R);
+            nxt.template track<false, XF>(st, cap);
+            s_dense<BG, ZC, NL, H, ET, XF, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi, xmine, xother);
+        } else if constexpr ((GI + 1) % 2 == H) { // the next group is this half's alone: its early part, here
+            GroupZ64<BG, ZC, GI + 1, NL, H> nxt;
+            nxt.template loads<false>(lds, R);
+            nxt.template track<false, XF>(st, cap);
+            s_crit<BG, ZC, NL, H, ET, XF, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+        } else {
+            s_early<BG, ZC, NL, H, ET, XF, GI + 1>(next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+        }
+    } else { // the dual row was the last group: row 0 (dual as well) follows
         next0.template loads<false>(lds, R);
         next0.template track<false, XF>(st, cap);
     }
@@ -207,12 +251,12 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     // One half's whole decode.  Instantiated twice; the branch on `half` is wave-uniform.
     auto run = [&](auto hc) {
         constexpr int H = decltype(hc)::value;
-        using O = Own<BG, NL, H>;
-        DecStateS<BG, NL, H, ZC, G::XL> st;
+        using O = Own<BG, NL, H, z64s_dual<BG, ZC, NL>()>;
+        DecStateS<BG, NL, H, ZC, G::XL, z64s_dual<BG, ZC, NL>()> st;
 #pragma unroll
         for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
         if constexpr (G::XL) { // half 0's extension rows first, then half 1's: [row][thread] bytes
-            st.xp = (lds_i8_t)(lds + G::XOFF + (size_t)(H == 0 ? 0 : Own<BG, NL, 0>::NEXT) * ZC + z);
+            st.xp = (lds_i8_t)(lds + G::XOFF + (size_t)(H == 0 ? 0 : Own<BG, NL, 0, false>::NEXT) * ZC + z);
         } else {
 #pragma unroll
             for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
@@ -250,13 +294,20 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
 #endif
         uint32_t esign_lo = 0, esign_hi = 0;
         GroupZ64<BG, ZC, 0, NL, H> g0;
-        if constexpr (H == 0) {
+        constexpr bool D0 = O::dual(0); // row 0 is worked on by both halves
+        // this thread's slot of the dual rows' exchange buffer, and its partner's (the other half's thread of the same row)
+        const uint32_t xmine = (uint32_t)G::XCHOFF + 8u * (uint32_t)(H * ZC + z), xother = (uint32_t)G::XCHOFF + 8u * (uint32_t)((1 - H) * ZC + z);
+        if constexpr (H == 0 || D0) {
             g0.template loads<false>(lds, R);
             g0.template track<false, XF>(st, cap);
         }
         for (int it = 1; it <= a.max_iter; ++it) {
             if constexpr (ETP) { esign_lo = 0; esign_hi = 0; }
-            if constexpr (H == 0) {
+            if constexpr (D0) {
+                GroupZ64<BG, ZC, 0, NL, H> nx;
+                s_dense<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi, xmine, xother);
+                g0 = nx;
+            } else if constexpr (H == 0) {
                 GroupZ64<BG, ZC, 0, NL, H> nx;
                 s_crit<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
                 g0 = nx;

@@ -88,16 +88,29 @@ template <int BG, int NL = BGT<BG>::ROWS> struct LayerGroups {
 // Ownership of layers by threads.  H < 0: a thread owns its check row in every layer (one thread per row of a codeword).
 // H = 0 / 1 ("split" kernels, nrldpc_decode_z64s.h): a row has TWO threads; the barrier groups alternate between them, so
 // each holds the messages (and extension LLRs) of every other group only -- about half the registers, twice the waves.
-template <int BG, int NL, int H> struct Own {
+template <int BG, int NL, int H, bool D = false> struct Own {
     using G = BGD<BG>;
     using LG = LayerGroups<BG, NL>;
     static constexpr bool mine(int L) { return H < 0 || LG::group_index(L) % 2 == H; }
     static constexpr int ncore(int L) { return G::row_ptr(L + 1) - G::row_ptr(L) - (L >= 4 ? 1 : 0); }
+    // "Dual" rows: the dense core rows 0..3 (BG1: 19 edges each, a quarter of all edges, each a barrier group of its own) are
+    // worked on by BOTH threads of a check row at once -- the edges alternate between the halves, each half searches its own
+    // edges for the two smallest magnitudes and the sign parity, the two partial results are exchanged through LDS (8 bytes
+    // per thread, one extra barrier), and each half then updates its own edges.  Without this one half carries a dense row
+    // alone while the other finishes the next row's few early edges and idles.
+    // D: the kernel variant works its dense rows dually (z64s_dual<BG, ZC, NL>(): where the exchange buffer costs no workgroup)
+    static constexpr bool dual(int L) { return D && H >= 0 && L < 4 && L < NL && ncore(L) >= 12; }
+    static constexpr bool owned(int L, int j) { return dual(L) ? (j % 2 == H) : mine(L); }
+    static constexpr int ncore_own(int L) {
+        int n = 0;
+        for (int j = 0; j < ncore(L); ++j) n += owned(L, j) ? 1 : 0;
+        return n;
+    }
     // index of the first message byte of layer L in this thread's compact message store
     static constexpr int core_base(int L) {
         if (H < 0) return G::core_base(L);
         int n = 0;
-        for (int l = 0; l < L; ++l) n += mine(l) ? ncore(l) : 0;
+        for (int l = 0; l < L; ++l) n += ncore_own(l);
         return n;
     }
     // index of layer L's extension LLR (L >= 4) in this thread's store
@@ -226,9 +239,9 @@ template <int BG> struct DecState {
 // are what the 80-VGPR budget of 6 waves per SIMD is short of: with them in registers the compiler spilled message words
 // to scratch, and the scratch traffic showed up as 1.5x the compulsory HBM bytes.
 typedef int8_t __attribute__((address_space(3))) * lds_i8_t;
-template <int BG, int NL, int H, int XS, bool XL> struct DecStateS;
-template <int BG, int NL, int H, int XS> struct DecStateS<BG, NL, H, XS, true> { // extension LLRs in LDS
-    uint32_t rm[Own<BG, NL, H>::NW];
+template <int BG, int NL, int H, int XS, bool XL, bool D> struct DecStateS;
+template <int BG, int NL, int H, int XS, bool D> struct DecStateS<BG, NL, H, XS, true, D> { // extension LLRs in LDS
+    uint32_t rm[Own<BG, NL, H, D>::NW];
     lds_i8_t xp; // this thread's byte of its half's extension row 0; row XI is XI * XS bytes further (an immediate offset)
     template <int XI, bool XF> __device__ __forceinline__ float ext() const {
         static_assert(!XF, "the split kernels keep no float copy of the extension LLRs");
@@ -236,9 +249,9 @@ template <int BG, int NL, int H, int XS> struct DecStateS<BG, NL, H, XS, true> {
     }
     template <int XI> __device__ __forceinline__ void set_ext(float q) { xp[XI * XS] = (int8_t)(int)q; }
 };
-template <int BG, int NL, int H, int XS> struct DecStateS<BG, NL, H, XS, false> { // extension LLRs in registers, int8 x4
-    uint32_t rm[Own<BG, NL, H>::NW];
-    uint32_t xq[Own<BG, NL, H>::NXW > 0 ? Own<BG, NL, H>::NXW : 1];
+template <int BG, int NL, int H, int XS, bool D> struct DecStateS<BG, NL, H, XS, false, D> { // extension LLRs in registers, int8 x4
+    uint32_t rm[Own<BG, NL, H, D>::NW];
+    uint32_t xq[Own<BG, NL, H, D>::NXW > 0 ? Own<BG, NL, H, D>::NXW : 1];
     template <int XI, bool XF> __device__ __forceinline__ float ext() const {
         static_assert(!XF, "the split kernels keep no float copy of the extension LLRs");
         return byte_to_f32<XI & 3>(xq[XI >> 2]);
