@@ -160,8 +160,11 @@ template <int LO, int HI, class F> __device__ __forceinline__ void dispatch_w(in
 
 // Split kernels (nrldpc_decode_z64s.h): are the dense core rows 0..3 worked on by both halves at once (Own::dual)?  BG1 only
 // (19 edges per row; BG2's rows 0..3 have 8-10), and only where the halves' exchange buffer (16 Z bytes of LDS) does not cost
-// a workgroup per CU.  Measured at BG1 Z = 384: all rows -1.8 % (fixed 25) / -2 % (parity stop); 5 / 13 / 24 rows -2 / -5 / -3 %
-// (fixed), -5 / -2 / -2 % (parity stop).  -DNRLDPC_Z64S_DUAL=0/1 forces it (A/B).
+// a workgroup per CU, and only for the 12-wave workgroups of which a CU holds two (Z = 384, 288): with three or more (smaller)
+// workgroups per CU the other workgroups already fill a dense row's idle half, and the extra barrier costs more than it saves.
+// Measured, one session each, against the same build without it -- Z = 384: all rows -1.8 % (fixed 25) / -2 % (parity stop);
+// 5 / 13 / 24 rows -2 / -5 / -3 % (fixed), -5 / -2 / -2 % (parity stop); Z = 288: -2.4 % / -4.9 %; Z = 208 / 224 / 240 / 256 (8-wave
+// workgroups): 0 / +2.3 / +1.3 / +0.3 % (fixed), +1...3 % (parity stop): off there.  -DNRLDPC_Z64S_DUAL=0/1 forces it (A/B).
 template <int BG, int ZC, int NL> constexpr bool z64s_dual() {
 #ifdef NRLDPC_Z64S_DUAL
     return NRLDPC_Z64S_DUAL != 0 && BG == 1;
@@ -172,7 +175,7 @@ template <int BG, int ZC, int NL> constexpr bool z64s_dual() {
     constexpr int by_waves = 24 / (2 * B::NWV) > 0 ? 24 / (2 * B::NWV) : 1;
     constexpr int w0 = (int)((160 * 1024) / base) < by_waves ? (int)((160 * 1024) / base) : by_waves;
     constexpr int w1 = (int)((160 * 1024) / (base + 16 * ZC)) < by_waves ? (int)((160 * 1024) / (base + 16 * ZC)) : by_waves;
-    return w1 == w0;
+    return w1 == w0 && by_waves <= 2;
 }
 
 // One base-graph layer for this thread's check row, split into phases so that the layers of a

@@ -88,14 +88,17 @@ def main():
     # BG2 28 with every row active) -- one loop in the row form, one per half in the split form
     ng = {1: 32, 2: 28}[a.bg]
     bars = [b[0] for b in body if b[1] == "s_barrier"]
-    spans = [sp for sp in spans if sum(1 for x in bars if sp[0] <= x <= sp[1]) == ng]
-    spans.sort(key=lambda t: t[1] - t[0])
-    keep = []
-    for sp in spans:
-        if all(sp[1] < k[0] or sp[0] > k[1] for k in keep):
-            keep.append(sp)
     want = 2 if a.form == "split" else 1
-    assert len(keep) == want, "expected %d iteration loop(s) with %d barriers, found %d" % (want, ng, len(keep))
+    keep = []
+    for nb in (ng, ng + 4):  # + 4: the split form's dual rows 0..3 have a second barrier each (Own::dual)
+        cand = sorted((sp for sp in spans if sum(1 for x in bars if sp[0] <= x <= sp[1]) == nb), key=lambda t: t[1] - t[0])
+        keep = []
+        for sp in cand:
+            if all(sp[1] < k[0] or sp[0] > k[1] for k in keep):
+                keep.append(sp)
+        if len(keep) == want:
+            break
+    assert len(keep) == want, "expected %d iteration loop(s) with %d (+4) barriers, found %d" % (want, ng, len(keep))
     loop = [b for b in body if any(lo <= b[0] <= hi for lo, hi in keep)]
     lo, hi = min(k[0] for k in keep), max(k[1] for k in keep)
     loop_bytes = sum(k[1] - k[0] for k in keep)
