@@ -26,14 +26,20 @@ capi = importlib.import_module("ldpc-3gpp-matlab_amd._capi")
 PEAK = 8.0e12
 
 
-def timed(fn, reps=10):
+def timed(fn, reps=10, inner=8):
+    """Device time per call: `inner` calls queued back to back between one event pair (so that the ~20 us a Python ->
+    ctypes -> hipLaunchKernel round trip takes is hidden behind the previous kernel, as it is in a pipeline), median over
+    `reps` such groups.  (Round 2 timed single calls: the short stage kernels read 2x their kernel-trace durations.)"""
     fn()
     torch.cuda.synchronize()
     ms = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); e1.synchronize()
-        ms.append(e0.elapsed_time(e1))
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record(); e1.synchronize()
+        ms.append(e0.elapsed_time(e1) / inner)
     return float(np.median(ms))
 
 
