@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 # NRLDPC_BUILD_AB=1: the A/B build -- both decoder forms (one / two threads per row) for every (BG, Z), chosen at run time by
-# NRLDPC_SPLIT=0/1 -- into its own library and object directory; load it with NRLDPC_LIB=<path> (tools/forms_session.sh)
+# NRLDPC_SPLIT=0/1 -- into its own library and object directory; load it with NRLDPC_LIB=<path> (tools/bench_all_z.py / tools/bench_configs.py with NRLDPC_SPLIT=0/1 and OUT_SUFFIX)
 AB = bool(os.environ.get("NRLDPC_BUILD_AB"))
 LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip_ab.so" if AB else "libnrldpc_hip.so")  # env override: kernel experiments
 OBJDIR = os.path.join(HERE, "build_ab" if AB else "build")
