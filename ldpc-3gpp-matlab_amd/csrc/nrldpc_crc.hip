@@ -227,6 +227,24 @@ __global__ __launch_bounds__(256) void nrldpc_crc_attach_lane_kernel(const CrcAt
     const int Ltb = a.B - a.A;
     const uint32_t top = 1u << (a.tb.L - 1), mask = (1u << a.tb.L) - 1u, poly = a.tb.poly & mask;
     uint32_t reg = 0;
+    const bool wide = ((a.A | a.K | Ltb) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.a) | reinterpret_cast<uintptr_t>(a.c)) & 3) == 0;
+    if (wide) { // four bits per load and store (rows are dword-aligned when A, L and K are multiples of 4)
+        for (int i = 0; i < a.A; i += 4) { // NRLDPCEncoder.m:70-82
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(src + i) & 0x01010101u;
+            reg = crc_step(reg, w, top, mask, poly);
+            reg = crc_step(reg, w >> 8, top, mask, poly);
+            reg = crc_step(reg, w >> 16, top, mask, poly);
+            reg = crc_step(reg, w >> 24, top, mask, poly);
+            *reinterpret_cast<uint32_t*>(c + i) = w;
+        }
+        for (int i = 0; i < Ltb; i += 4) {
+            const uint32_t w = ((reg >> (Ltb - 1 - i)) & 1u) | (((reg >> (Ltb - 2 - i)) & 1u) << 8) |
+                               (((reg >> (Ltb - 3 - i)) & 1u) << 16) | (((reg >> (Ltb - 4 - i)) & 1u) << 24);
+            *reinterpret_cast<uint32_t*>(c + a.A + i) = w;
+        }
+        for (int i = a.Kp; i < a.K; i += 4) *reinterpret_cast<uint32_t*>(c + i) = 0u; // fillers (:120-122,153)
+        return;
+    }
     for (int i = 0; i < a.A; ++i) { // NRLDPCEncoder.m:70-82
         const uint8_t v = src[i] & 1u;
         reg = crc_step(reg, v, top, mask, poly);

@@ -503,7 +503,9 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
                                              int w, const DecArgs& a, float cap, uint32_t& esign_lo,
                                              uint32_t& esign_hi) {
     constexpr int NG = LayerGroups<BG, NL>::ngroups();
-    __syncthreads(); // ends group GI-1 (for GI == 0: the previous iteration / the prologue)
+    // ends group GI-1.  With early termination the parity pass between two iterations ends with a barrier of its own (and the
+    // first iteration follows the prologue's), so group 0 needs none -- the waves that only keep the barrier count skip it too.
+    if constexpr (!(ET && GI == 0)) __syncthreads();
 #if NRLDPC_Z64_POSTBAR
     // Variant: the group's own early part (its LDS reads were issued before the barrier) is tracked AFTER the barrier, in
     // the shadow of the late reads' LDS round trip, instead of before it; only the next group's early READS precede the
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         if (!all_done) {
             done = true;
             for (; it <= a.max_iter; ++it) {
-                for (int g = 0; g < LGN::ngroups(); ++g) __syncthreads();
+                for (int g = 0; g < LGN::ngroups() - 1; ++g) __syncthreads(); // (see pipeline_z64: group 0 has no barrier here)
                 if (parity_pass(it)) break;
             }
         }
