@@ -177,6 +177,24 @@ template <int BG, int ZC, int NL> constexpr bool z64s_dual() {
     constexpr int w1 = (int)((160 * 1024) / (base + 16 * ZC)) < by_waves ? (int)((160 * 1024) / (base + 16 * ZC)) : by_waves;
     return w1 == w0 && by_waves <= 2;
 }
+// ... and are its barrier groups single layers (LayerGroups<.., SG>: 46 / 42 barriers per iteration instead of 32 / 28)?  The row
+// form wants as few barriers as possible; the split form's barriers are hand-overs between the halves, and a merged pair of
+// layers makes one half's interval twice as long as the other's next one.  Measured against the merged groups, one session:
+// BG1 Z = 384 -3.2 % (fixed 25) / -3.9 % (parity stop), 5 / 13 / 24 rows 0 / 0 / -1 % and -1 %; Z = 288 -3.0 / -1.5 %; the 8-wave
+// workgroups Z = 256 / 240 / 208: 0...-1 % fixed but +1...4 % with the parity stop -- off; Z <= 128: within +-1.4 %, off.
+// BG2 (rows 0..3 are not dual there): Z = 256 / 240 / 224 / 208: 0 / -1.1 / -3.2 / -3.4 % fixed, -4.5 / -4.7 / -9.0 / -8.8 % parity
+// stop; Z = 64 / 60 / 52: 0 / -2.8 / +1 % and 0 / -2.3 / -2 %: on.  -DNRLDPC_Z64S_SINGLE=0/1 forces it (A/B).
+template <int BG, int ZC, int NL> constexpr bool z64s_single() {
+#ifdef NRLDPC_Z64S_SINGLE
+    return NRLDPC_Z64S_SINGLE != 0;
+#endif
+    return BG == 2 || 24 / (2 * Z64<BG, ZC, 1, NL>::NWV) <= 2;
+}
+template <int BG, int ZC, int NL> constexpr int z64s_variant() {
+    return (z64s_dual<BG, ZC, NL>() ? SPLIT_DUAL : 0) | (z64s_single<BG, ZC, NL>() ? SPLIT_SINGLE : 0);
+}
+// the barrier-group table of a kernel form (H < 0: one thread per check row)
+template <int BG, int ZC, int NL, int H> using LGof = LayerGroups<BG, NL, (H >= 0 && z64s_single<BG, ZC, NL>())>;
 
 // One base-graph layer for this thread's check row, split into phases so that the layers of a
 // column-disjoint barrier group can issue all their LDS reads first and share one mirror dispatch.
@@ -186,7 +204,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
     static constexpr int deg = G::row_ptr(L + 1) - e0;
     static constexpr bool HAS_EXT = (L >= 4);
     static constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
-    using OW = Own<BG, NL, H, (H >= 0 && z64s_dual<BG, ZC, NL>())>;
+    using OW = Own<BG, NL, H, (H >= 0 ? z64s_variant<BG, ZC, NL>() : 0)>;
     static constexpr int ce0 = OW::core_base(L); // first message byte of this layer in the thread's store
     static constexpr int XI = HAS_EXT ? OW::ext_index(L) : 0; // its extension LLR there
     static constexpr bool DUALROW = OW::dual(L);  // the row's edges alternate between the two halves
@@ -211,7 +229,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
     // barrier group in front of this layer's group (cyclically), otherwise "early": early edges may be read
     // and folded into the min search BEFORE the barrier that separates the two groups.
     static constexpr unsigned long long prev_written() {
-        using LG = LayerGroups<BG, NL>;
+        using LG = LGof<BG, ZC, NL, H>;
         return LG::group_mask((LG::group_index(L) + LG::ngroups() - 1) % LG::ngroups());
     }
     static constexpr bool is_late(int j) { return (prev_written() >> G::col(e0 + j)) & 1ull; }
@@ -453,7 +471,7 @@ __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uin
 // ---- software pipeline over barrier groups (FULL && PLAIN kernels) -------------------------------------
 // Group gi's layers; `early` = loads + min search over the edges that do not depend on the previous group.
 template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct GroupZ64 {
-    using LG = LayerGroups<BG, NL>;
+    using LG = LGof<BG, ZC, NL, H>;
     static constexpr int GS = LG::group_first(GI);
     static constexpr int N = LG::group_last(GS) - GS + 1;
     static_assert(N >= 1 && N <= 3, "group size");
@@ -937,9 +955,10 @@ static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
 namespace nrldpc {
 
 // Which form serves a (BG, Z, layer count): the measured choice, z64_split_default -- both forms timed on the MI355X for
-// every pair at 25 fixed iterations and for every BASELINE configuration (profiles/r03_forms_all_z.json,
-// r03_forms_configs.json).  The split form wins where two of its workgroups (or more) fill a CU's wave slots evenly:
-// BG1 +5...16 % (Z = 384: +11 %, 288: +16 %), small BG2 sizes +12...26 %; it loses where a workgroup of 2 Z/B waves leaves
+// every pair at 25 fixed iterations and with the parity-check stop, in one session (tools/bench_forms.py,
+// profiles/r03_forms.json), and for every BASELINE configuration (r03_forms_configs_*.json).  The split form wins where two of
+// its workgroups (or more) fill a CU's wave slots evenly: BG1 -4...-19 % of the row form's time (Z = 384: -15 %, 288: -19 %),
+// BG2 Z <= 128 and 208...256 -3...-18 % (-2...-26 % with the parity stop); it loses where a workgroup of 2 Z/B waves leaves
 // slots empty (Z = 320: 10-wave workgroups, Z = 352: 16) or spreads unevenly over the 4 SIMDs (6-wave workgroups, Z = 144,
 // 192), and on BG2 Z = 384, whose one-thread-per-row form already runs 6 waves per SIMD with four codewords per CU.
 // A library built with -DNRLDPC_Z64_AB carries both forms for every pair and takes NRLDPC_SPLIT=0 / 1 from the
@@ -954,7 +973,8 @@ template <int BG, int ZC, int NL> constexpr bool z64_split_default() {
     if (BG == 1)
         return ZC == 60 || ZC == 64 || ZC == 104 || ZC == 112 || ZC == 120 || ZC == 128 || ZC == 176 || ZC == 208 || ZC == 224 ||
                ZC == 240 || ZC == 256 || ZC == 288 || ZC == 384;
-    return ZC == 52 || ZC == 60 || ZC == 64 || ZC == 208 || ZC == 224 || ZC == 240 || ZC == 256;
+    return ZC == 52 || ZC == 60 || ZC == 64 || ZC == 88 || ZC == 96 || ZC == 104 || ZC == 112 || ZC == 120 || ZC == 128 ||
+           ZC == 208 || ZC == 224 || ZC == 240 || ZC == 256;
 }
 #ifdef NRLDPC_Z64_AB
 constexpr bool z64_ab = true;

@@ -35,7 +35,7 @@ namespace nrldpc {
 
 template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
     using B = Z64<BG, ZC, 1, NL>;
-    static constexpr int NG = LayerGroups<BG, NL>::ngroups();
+    static constexpr int NG = LGof<BG, ZC, NL, 0>::ngroups();
     static constexpr int THREADS = 2 * B::TPC;
     static constexpr bool usable() { return THREADS <= 1024 && NG >= 2; }
     // rings + trailing guard + flags [+ the extension-column channel LLRs, one int8 per extension row and row-thread]
@@ -49,7 +49,7 @@ template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
         return by_waves < by_lds ? by_waves : by_lds;
     }
     // dual rows (Own::dual): the exchange buffer of the two halves' partial searches, 8 bytes per thread
-    static constexpr bool DUAL = Own<BG, NL, 0, z64s_dual<BG, ZC, NL>()>::dual(0);
+    static constexpr bool DUAL = Own<BG, NL, 0, z64s_variant<BG, ZC, NL>()>::dual(0);
     static constexpr size_t XCHBYTES = DUAL ? (size_t)2 * ZC * 8 : 0;
     static constexpr bool XL = wgs_per_cu(XOFF + XCHBYTES + XBYTES) == wgs_per_cu(XOFF + XCHBYTES);
     static constexpr size_t XCHOFF = (XOFF + (XL ? XBYTES : 0) + 7) & ~(size_t)7;
@@ -66,7 +66,7 @@ template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
 __device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds,
                                        const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
                                        float cap, uint32_t& esign_lo, uint32_t& esign_hi) {
-    constexpr int NG = LayerGroups<BG, NL>::ngroups();
+    constexpr int NG = LGof<BG, ZC, NL, 0>::ngroups();
     // ends interval GI-1: group GI-1's writes are visible.  With early termination the parity pass between two iterations
     // ends with a barrier of its own (and the first iteration follows the prologue's), so interval 0 needs none.
     if constexpr (!(ET && GI == 0)) __syncthreads();
@@ -82,7 +82,7 @@ __device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ6
     }
     if constexpr (GI + 1 < NG) {
         s_early<BG, ZC, NL, H, ET, XF, GI + 1>(next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
-    } else if constexpr (H == 0 || Own<BG, NL, H, z64s_dual<BG, ZC, NL>()>::dual(0)) { // (a dual row 0: both halves prepare their own edges of it)
+    } else if constexpr (H == 0 || Own<BG, NL, H, z64s_variant<BG, ZC, NL>()>::dual(0)) { // (a dual row 0: both halves prepare their own edges of it)
         // odd group count: this half owns the last group AND group 0, whose early part it runs right here (the one
         // interval per iteration that is software-pipelined within a wave, as in pipeline_z64)
         next0.template loads<false>(lds, R);
@@ -95,14 +95,14 @@ template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
 __device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)],
                                         uint32_t RA, uint32_t RB, int w, const DecArgs& a, float cap, uint32_t& esign_lo,
                                         uint32_t& esign_hi) {
-    constexpr int NG = LayerGroups<BG, NL>::ngroups();
+    constexpr int NG = LGof<BG, ZC, NL, 0>::ngroups();
     if constexpr (!(ET && GI == 0)) __syncthreads(); // see s_crit
     if constexpr (GI + 1 < NG) {
         GroupZ64<BG, ZC, GI + 1, NL, H> nxt;
         nxt.template loads<false>(lds, R); // columns group GI does not write
         nxt.template track<false, XF>(st, cap);
         s_crit<BG, ZC, NL, H, ET, XF, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
-    } else if constexpr (H == 0 || Own<BG, NL, H, z64s_dual<BG, ZC, NL>()>::dual(0)) { // even group count: the last group is the other half's, group 0 is this one's
+    } else if constexpr (H == 0 || Own<BG, NL, H, z64s_variant<BG, ZC, NL>()>::dual(0)) { // even group count: the last group is the other half's, group 0 is this one's
         next0.template loads<false>(lds, R);
         next0.template track<false, XF>(st, cap);
     }
@@ -114,8 +114,8 @@ template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
 __device__ __forceinline__ void s_dense(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds,
                                         const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
                                         float cap, uint32_t& esign_lo, uint32_t& esign_hi, uint32_t xmine, uint32_t xother) {
-    using O = Own<BG, NL, H, z64s_dual<BG, ZC, NL>()>;
-    using LG = LayerGroups<BG, NL>;
+    using O = Own<BG, NL, H, z64s_variant<BG, ZC, NL>()>;
+    using LG = LGof<BG, ZC, NL, 0>;
     constexpr int NG = LG::ngroups();
     static_assert(LG::group_last(LG::group_first(GI)) == LG::group_first(GI), "a dual row is a barrier group of its own");
     if constexpr (!(ET && GI == 0)) __syncthreads(); // see s_crit
@@ -151,7 +151,7 @@ __device__ __forceinline__ void s_dense(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ
 template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS>
 __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_decode_z64s_kernel(const DecArgs a) {
     using G = Z64S<BG, ZC, NL>;
-    using LGN = LayerGroups<BG, NL>;
+    using LGN = LGof<BG, ZC, NL, 0>;
     static_assert(G::usable(), "split kernel: at most 1024 threads");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -251,12 +251,12 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_
     // One half's whole decode.  Instantiated twice; the branch on `half` is wave-uniform.
     auto run = [&](auto hc) {
         constexpr int H = decltype(hc)::value;
-        using O = Own<BG, NL, H, z64s_dual<BG, ZC, NL>()>;
-        DecStateS<BG, NL, H, ZC, G::XL, z64s_dual<BG, ZC, NL>()> st;
+        using O = Own<BG, NL, H, z64s_variant<BG, ZC, NL>()>;
+        DecStateS<BG, NL, H, ZC, G::XL, z64s_variant<BG, ZC, NL>()> st;
 #pragma unroll
         for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
         if constexpr (G::XL) { // half 0's extension rows first, then half 1's: [row][thread] bytes
-            st.xp = (lds_i8_t)(lds + G::XOFF + (size_t)(H == 0 ? 0 : Own<BG, NL, 0, false>::NEXT) * ZC + z);
+            st.xp = (lds_i8_t)(lds + G::XOFF + (size_t)(H == 0 ? 0 : Own<BG, NL, 0, z64s_variant<BG, ZC, NL>()>::NEXT) * ZC + z);
         } else {
 #pragma unroll
             for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;

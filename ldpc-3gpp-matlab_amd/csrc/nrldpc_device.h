@@ -42,7 +42,10 @@ template <int BG> struct BGD : BGT<BG> {
 // 32 barriers per iteration instead of 46, BG2 28 instead of 42.  Groups are formed greedily in table
 // order (the processing order is NOT changed).  NL = number of active layers (rows 0..NL-1): a pruned layer count
 // known at compile time gets its own group table, so the cyclic "next group" of the last group is group 0 again.
-template <int BG, int NL = BGT<BG>::ROWS> struct LayerGroups {
+// SG ("single"): every layer a group of its own -- always legal (a barrier in front of every layer IS the sequential schedule);
+// the split kernels of the 12-wave workgroups use it (z64s_single, nrldpc_decode_z64s.h): their two halves alternate per group,
+// and one-layer groups keep the two halves' shares of every interval closer than the merged pairs do.
+template <int BG, int NL = BGT<BG>::ROWS, bool SG = false> struct LayerGroups {
     using G = BGD<BG>;
     static_assert(NL >= 4 && NL <= BGT<BG>::ROWS, "active layer count");
     static constexpr unsigned long long colmask(int L) {
@@ -65,7 +68,7 @@ template <int BG, int NL = BGT<BG>::ROWS> struct LayerGroups {
         unsigned long long acc = 0;
         for (int l = 0; l < NL; ++l) {
             const unsigned long long m = colmask(l);
-            if (l == 0 || (acc & m)) { start = l; acc = m; ++gi; t.gfirst[gi] = l; t.gmask[gi] = 0; } else acc |= m;
+            if (SG || l == 0 || (acc & m)) { start = l; acc = m; ++gi; t.gfirst[gi] = l; t.gmask[gi] = 0; } else acc |= m;
             t.gstart[l] = start;
             t.gindex[l] = gi;
             t.gmask[gi] |= m;
@@ -88,9 +91,11 @@ template <int BG, int NL = BGT<BG>::ROWS> struct LayerGroups {
 // Ownership of layers by threads.  H < 0: a thread owns its check row in every layer (one thread per row of a codeword).
 // H = 0 / 1 ("split" kernels, nrldpc_decode_z64s.h): a row has TWO threads; the barrier groups alternate between them, so
 // each holds the messages (and extension LLRs) of every other group only -- about half the registers, twice the waves.
-template <int BG, int NL, int H, bool D = false> struct Own {
+// V: variant bits of a split kernel (z64s_variant<BG, ZC, NL>()): 1 = dual dense rows, 2 = one-layer barrier groups.
+constexpr int SPLIT_DUAL = 1, SPLIT_SINGLE = 2;
+template <int BG, int NL, int H, int V = 0> struct Own {
     using G = BGD<BG>;
-    using LG = LayerGroups<BG, NL>;
+    using LG = LayerGroups<BG, NL, (H >= 0 && (V & SPLIT_SINGLE) != 0)>;
     static constexpr bool mine(int L) { return H < 0 || LG::group_index(L) % 2 == H; }
     static constexpr int ncore(int L) { return G::row_ptr(L + 1) - G::row_ptr(L) - (L >= 4 ? 1 : 0); }
     // "Dual" rows: the dense core rows 0..3 (BG1: 19 edges each, a quarter of all edges, each a barrier group of its own) are
@@ -98,8 +103,8 @@ template <int BG, int NL, int H, bool D = false> struct Own {
     // edges for the two smallest magnitudes and the sign parity, the two partial results are exchanged through LDS (8 bytes
     // per thread, one extra barrier), and each half then updates its own edges.  Without this one half carries a dense row
     // alone while the other finishes the next row's few early edges and idles.
-    // D: the kernel variant works its dense rows dually (z64s_dual<BG, ZC, NL>(): where the exchange buffer costs no workgroup)
-    static constexpr bool dual(int L) { return D && H >= 0 && L < 4 && L < NL && ncore(L) >= 12; }
+    // V & SPLIT_DUAL: the kernel variant works its dense rows dually (z64s_dual<BG, ZC, NL>(): where the exchange buffer costs no workgroup)
+    static constexpr bool dual(int L) { return (V & SPLIT_DUAL) != 0 && H >= 0 && L < 4 && L < NL && ncore(L) >= 12; }
     static constexpr bool owned(int L, int j) { return dual(L) ? (j % 2 == H) : mine(L); }
     static constexpr int ncore_own(int L) {
         int n = 0;
@@ -239,9 +244,9 @@ template <int BG> struct DecState {
 // are what the 80-VGPR budget of 6 waves per SIMD is short of: with them in registers the compiler spilled message words
 // to scratch, and the scratch traffic showed up as 1.5x the compulsory HBM bytes.
 typedef int8_t __attribute__((address_space(3))) * lds_i8_t;
-template <int BG, int NL, int H, int XS, bool XL, bool D> struct DecStateS;
-template <int BG, int NL, int H, int XS, bool D> struct DecStateS<BG, NL, H, XS, true, D> { // extension LLRs in LDS
-    uint32_t rm[Own<BG, NL, H, D>::NW];
+template <int BG, int NL, int H, int XS, bool XL, int V> struct DecStateS;
+template <int BG, int NL, int H, int XS, int V> struct DecStateS<BG, NL, H, XS, true, V> { // extension LLRs in LDS
+    uint32_t rm[Own<BG, NL, H, V>::NW];
     lds_i8_t xp; // this thread's byte of its half's extension row 0; row XI is XI * XS bytes further (an immediate offset)
     template <int XI, bool XF> __device__ __forceinline__ float ext() const {
         static_assert(!XF, "the split kernels keep no float copy of the extension LLRs");
@@ -249,9 +254,9 @@ template <int BG, int NL, int H, int XS, bool D> struct DecStateS<BG, NL, H, XS,
     }
     template <int XI> __device__ __forceinline__ void set_ext(float q) { xp[XI * XS] = (int8_t)(int)q; }
 };
-template <int BG, int NL, int H, int XS, bool D> struct DecStateS<BG, NL, H, XS, false, D> { // extension LLRs in registers, int8 x4
-    uint32_t rm[Own<BG, NL, H, D>::NW];
-    uint32_t xq[Own<BG, NL, H, D>::NXW > 0 ? Own<BG, NL, H, D>::NXW : 1];
+template <int BG, int NL, int H, int XS, int V> struct DecStateS<BG, NL, H, XS, false, V> { // extension LLRs in registers, int8 x4
+    uint32_t rm[Own<BG, NL, H, V>::NW];
+    uint32_t xq[Own<BG, NL, H, V>::NXW > 0 ? Own<BG, NL, H, V>::NXW : 1];
     template <int XI, bool XF> __device__ __forceinline__ float ext() const {
         static_assert(!XF, "the split kernels keep no float copy of the extension LLRs");
         return byte_to_f32<XI & 3>(xq[XI >> 2]);

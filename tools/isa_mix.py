@@ -87,10 +87,11 @@ def main():
     # the iteration loop(s): the innermost backward branches that enclose exactly one barrier per barrier group (BG1 32,
     # BG2 28 with every row active) -- one loop in the row form, one per half in the split form
     ng = {1: 32, 2: 28}[a.bg]
+    ng1 = {1: 46, 2: 42}[a.bg]  # the split form's one-layer groups (z64s_single)
     bars = [b[0] for b in body if b[1] == "s_barrier"]
     want = 2 if a.form == "split" else 1
     keep = []
-    for nb in (ng, ng + 4):  # + 4: the split form's dual rows 0..3 have a second barrier each (Own::dual)
+    for nb in ((ng,) if a.form == "row" else (ng, ng + 4, ng1, ng1 + 4)):  # + 4: the split form's dual rows 0..3 have a second barrier each (Own::dual)
         cand = sorted((sp for sp in spans if sum(1 for x in bars if sp[0] <= x <= sp[1]) == nb), key=lambda t: t[1] - t[0])
         keep = []
         for sp in cand:
