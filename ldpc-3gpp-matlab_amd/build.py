@@ -20,13 +20,17 @@ OBJDIR = os.path.join(HERE, "build_ab" if AB else "build")
 SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_channel.hip",
            "nrldpc_expand.hip", "nrldpc_capi.hip", "nrldpc_host_quant.cpp"]  # .cpp: host-only C++ (no device pass)
 Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
+Z64P_SOURCE = "nrldpc_decode_z64p_inst.hip"
 # = NRLDPC_Z64_LIST (nrldpc_kernels.h): the sizes where the compile-time-Z kernel beats the run-time-Z one
 Z64_BG1 = (60, 64, 104, 112, 120, 128, 144, 176, 192, 208, 224, 240, 256, 288, 320, 352, 384)
 Z64_BG2 = (52, 60, 64, 88, 96, 104, 112, 120, 128, 144, 192, 208, 224, 240, 256, 288, 320, 352, 384)
 Z64_PAIRS = [(1, z) for z in Z64_BG1] + [(2, z) for z in Z64_BG2]
+# = NRLDPC_Z64P_LIST: the packed geometry (several codewords per wave), every lifting size <= 32
+Z64P_Z = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32)
+Z64P_PAIRS = [(bg, z) for bg in (1, 2) for z in Z64P_Z]
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7)]
-HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_wave.h", "nrldpc_host_quant.h"]
+HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DNRLDPC_Z64_AB"] if AB else [])
 
 
@@ -38,7 +42,7 @@ def _hipcc():
 
 
 def _deps():
-    d = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + [Z64_SOURCE]]
+    d = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + [Z64_SOURCE, Z64P_SOURCE]]
     d += [os.path.join(INCLUDE, "nrldpc.h"), os.path.join(INCLUDE, "nr_bg_tables.h"), os.path.abspath(__file__)]
     return [p for p in d if os.path.exists(p)]
 
@@ -54,7 +58,8 @@ def source_id():
     return h.hexdigest()[:16]
 
 
-KERNEL_SOURCES = ["nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64_inst.hip", "nrldpc_decode.hip",
+KERNEL_SOURCES = ["nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_decode_z64_inst.hip",
+                  "nrldpc_decode_z64p_inst.hip", "nrldpc_decode.hip",
                   "nrldpc_device.h", "nrldpc_kernels.h"]
 
 
@@ -96,6 +101,8 @@ def build_lib(force=False, verbose=False, jobs=None):
              for f in SOURCES]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d.o" % (bg, z)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64_PAIRS]
+    units += [(os.path.join(CSRC, Z64P_SOURCE), os.path.join(OBJDIR, "z64p_%d_%d.o" % (bg, z)),
+               ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64P_PAIRS]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64_NL]
     # An object is reused only when it was compiled from exactly these inputs: contents of its source and of every

@@ -327,8 +327,21 @@ bool has_z64_kernel(int bg, int Z) {
     return false;
 }
 
+bool has_z64p_kernel(int bg, int Z) {
+    if (force_generic_env()) return false;
+#define NRLDPC_Z64P_CASE(b, z) if (bg == b && Z == z) return true;
+    NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
+#undef NRLDPC_Z64P_CASE
+    return false;
+}
+
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
     const bool force_generic = force_generic_env();
+    if (!force_generic && !a.app && a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS)) { // the packed builds: all rows, hard output
+#define NRLDPC_Z64P_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64p_##b##_##z(a, stream);
+        NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
+#undef NRLDPC_Z64P_CASE
+    }
 #define NRLDPC_Z64_CASE(b, z) if (!force_generic && bg == b && a.Z == z) return launch_decode_z64_##b##_##z(a, stream);
     NRLDPC_Z64_LIST(NRLDPC_Z64_CASE)
 #undef NRLDPC_Z64_CASE

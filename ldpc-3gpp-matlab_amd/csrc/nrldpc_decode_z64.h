@@ -47,11 +47,38 @@ constexpr int z64_set_index(int Z) {
     return -1;
 }
 
+// "Packed" geometry (nrldpc_decode_z64p.h): lifting sizes too small to fill a wave with one codeword.  A workgroup's row
+// lanes g = 0 .. Z*NCW-1 (RW waves of 64 per half) carry NCW whole codewords, codeword index fastest: g = z*NCW + c.  A column
+// of the workgroup's LDS image is [ring: Z*NCW words][mirror: the same again][pad: as much again], word u + P*NCW holding ring
+// position (z + P) of codeword c -- consecutive lanes touch consecutive words (no bank conflicts for any Z), the rotation is an
+// instruction immediate exactly as in the block geometry (its "block" is the whole ring: one base address per thread), reads
+// never wrap because the mirror is a full copy, and the twin writes' out-of-range lanes fall into the pad in front (the previous
+// column's; a guard before column 0) or behind.
+constexpr bool z64_packed(int Z) {
+#ifdef NRLDPC_Z64_PACK
+    return NRLDPC_Z64_PACK != 0;
+#endif
+    return Z <= 32;
+}
+// row waves per half of a packed workgroup: one, unless that leaves more than a fifth of the lanes empty and two fill more
+// (Z = 22, 24).  Measured (one session, fixed 25 / parity stop): two-wave halves gain 2-10 % at fixed iterations where they
+// fill more lanes but lose 10-25 % with the parity stop on BG1 (a workgroup lives until its last codeword converges, and
+// holds twice as many); three-wave halves (6-wave workgroups, three per CU) lose 14-48 %.
+constexpr int z64p_rw(int Z) {
+#ifdef NRLDPC_Z64P_RW
+    return NRLDPC_Z64P_RW;
+#endif
+    const int f1 = (64 / Z) * Z, f2 = (128 / Z) * Z;
+    return (f1 * 5 < 64 * 4 && f2 > 2 * f1) ? 2 : 1;
+}
+constexpr int z64p_ncw(int Z) { return 64 * z64p_rw(Z) / Z; } // codewords per packed workgroup
+
 // Rows per wave ("block"): 64 when 64 | Z, else the largest divisor of Z below 64 that is a multiple of 4.
 // A wave then owns B consecutive rows and its lanes B..63 retire at kernel entry (Z = 240 -> 4 waves of 60
 // rows, 94 % of the lanes busy; the run-time-Z kernel fills every lane but pays 12 VALU cycles per edge for
 // the ring address and runs at 0.55-0.7 of this kernel's rate).
 constexpr int z64_blk(int Z) {
+    if (z64_packed(Z)) return Z; // the whole ring: every shift is an offset from one base address
     if (Z % 64 == 0) return 64;
     for (int b = 60; b >= 4; b -= 4)
         if (Z % b == 0) return b;
@@ -111,13 +138,18 @@ template <int BG, int ZC, int NCWG, int NL = BGT<BG>::ROWS> constexpr int z64_wp
 template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROWS> struct Z64 : BGD<BG> {
     static constexpr int NL = NL_;
     static constexpr int NNZA = BGD<BG>::row_ptr(NL_); // edges of the active rows
+    static constexpr bool PACKED = z64_packed(ZC);
     static constexpr int BLK = z64_blk(ZC);             // rows (ring words) per wave
-    static_assert(BLK >= 4 && ZC % BLK == 0, "no usable block size for this lifting size");
+    static_assert(BLK >= (PACKED ? 2 : 4) && ZC % BLK == 0, "no usable block size for this lifting size");
     static constexpr int NWV = ZC / BLK;                // waves per codeword
     static constexpr int TPC = NWV * 64;                // threads per codeword (lanes BLK..63 of a wave retire)
-    static constexpr int GUARD = 256;                   // bytes: 64 never-read words in front of every ring
-    static constexpr int CS = GUARD + (ZC + 64) * 4;    // column stride in bytes (guard + ring + mirror)
-    static constexpr int CWS = BGD<BG>::NC * CS;        // codeword stride in bytes
+    static constexpr int PW = PACKED ? z64p_ncw(ZC) : 1; // packed: words between consecutive ring positions (= codewords per workgroup)
+    static constexpr int GUARD = PACKED ? 4 * ZC * PW : 256; // bytes: never-read words in front of every ring (packed: of column 0)
+    static constexpr int CS = PACKED ? 12 * ZC * PW : GUARD + (ZC + 64) * 4; // column stride in bytes (guard + ring + mirror | ring + mirror + pad)
+    static constexpr int CWS = BGD<BG>::NC * CS;        // codeword stride in bytes (packed: of the workgroup's whole image)
+    // a shift P as (index of the thread's base address, byte offset from it)
+    static constexpr int ridx(int P) { return P / BLK; }
+    static constexpr int roff(int P) { return 4 * (P % BLK) * PW; }
     static constexpr int NCWG = NCWG_;                  // codewords per workgroup
     static constexpr int ILS = z64_set_index(ZC);
     static constexpr int shift(int e) { return (BG == 1 ? nr_bg1_shift[ILS][e] : nr_bg2_shift[ILS][e < NR_BG2_NNZ ? e : 0]) % ZC; }
@@ -221,7 +253,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int P = G::shift(e0 + j);
-            t[j] = *reinterpret_cast<const float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK));
+            t[j] = *reinterpret_cast<const float*>(lds + R[G::ridx(P)] + G::col(e0 + j) * G::CS + G::roff(P));
         });
     }
 
@@ -241,7 +273,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
             constexpr int j = decltype(jc)::value;
             if constexpr (LayerZ64::is_late(j) == LATE && LayerZ64::owned(j)) {
                 constexpr int P = G::shift(e0 + j);
-                t[j] = *reinterpret_cast<const float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK));
+                t[j] = *reinterpret_cast<const float*>(lds + R[G::ridx(P)] + G::col(e0 + j) * G::CS + G::roff(P));
             }
         });
     }
@@ -337,7 +369,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
                 f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
                 const float v = tj + r;
                 t[j] = v;
-                *reinterpret_cast<float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK)) = v;
+                *reinterpret_cast<float*>(lds + R[G::ridx(P)] + G::col(e0 + j) * G::CS + G::roff(P)) = v;
             }
         });
     }
@@ -382,7 +414,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
             f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
             const float v = tj + r;
             t[j] = v; // kept for the mirror pass
-            *reinterpret_cast<float*>(lds + R[P / G::BLK] + G::col(e0 + j) * G::CS + 4 * (P % G::BLK)) = v;
+            *reinterpret_cast<float*>(lds + R[G::ridx(P)] + G::col(e0 + j) * G::CS + G::roff(P)) = v;
         });
     }
 
@@ -396,7 +428,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
             constexpr int j = decltype(jc)::value;
             constexpr int P = G::shift(e0 + j);
             constexpr int ka = P / G::BLK;
-            constexpr int off = G::col(e0 + j) * G::CS + 4 * (P % G::BLK);
+            constexpr int off = G::col(e0 + j) * G::CS + G::roff(P);
             if constexpr (LayerZ64::owned(j) && ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
                                                  (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV))) {
                 if constexpr (G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV)
@@ -597,7 +629,7 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);
         constexpr int P = G::shift(e0 + j);
-        p ^= fbits(*reinterpret_cast<const float*>(lds + R[P / G::BLK] + c * G::CS + 4 * (P % G::BLK)));
+        p ^= fbits(*reinterpret_cast<const float*>(lds + R[G::ridx(P)] + c * G::CS + G::roff(P)));
     });
     p >>= 31;
     if constexpr (HAS_EXT) p ^= (L - 4 < 32 ? esign_lo >> ((L - 4) & 31) : esign_hi >> ((L - 36) & 31)) & 1u;

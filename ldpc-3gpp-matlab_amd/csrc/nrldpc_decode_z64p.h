@@ -1,0 +1,223 @@
+// nrldpc_decode_z64p.h -- the split decoder (nrldpc_decode_z64s.h: two threads per check row, barrier groups alternating
+// between them) in the PACKED geometry (z64_packed, nrldpc_decode_z64.h): lifting sizes too small to fill a wave with one
+// codeword.  A workgroup is 2 x RW waves and decodes NCW = floor(64 RW / Z) codewords at once, row lane g = z*NCW + c.  The
+// per-layer code (LayerZ64 / GroupZ64 / s_crit / s_early) is the block geometry's, unchanged: only the base addresses differ.
+// Replaces the run-time-Z kernel (nrldpc_decode.hip) for these sizes when every row is active and no soft output is asked for.
+//
+// Early termination: the codewords of a workgroup converge at different iterations.  Nothing is frozen: a codeword that passes
+// its parity check has its hard decisions (and iteration count) written out AT THAT ITERATION by its own lanes, and then simply
+// keeps iterating until the last codeword of the workgroup is done -- what happens to its values afterwards reaches nobody.  So
+// the iteration loop has no divergent control flow (a per-lane `done` around it would wrap 80 state registers in exec-mask phis).
+#ifndef NRLDPC_DECODE_Z64P_H
+#define NRLDPC_DECODE_Z64P_H
+#include "nrldpc_decode_z64.h"
+
+namespace nrldpc {
+
+template <int BG, int ZC> struct Z64P : Z64<BG, ZC, 1, BGT<BG>::ROWS> {
+    using B = Z64<BG, ZC, 1, BGT<BG>::ROWS>;
+    static_assert(B::PACKED && B::NWV == 1, "packed geometry");
+    static constexpr int RW = z64p_rw(ZC);       // row waves per half
+    static constexpr int NCW = z64p_ncw(ZC);     // codewords per workgroup
+    static constexpr int NROW = ZC * NCW;        // row lanes in use (of 64 RW)
+    static constexpr int THREADS = 2 * RW * 64;
+    static_assert(NCW >= 1 && NROW <= 64 * RW && NCW + 1 <= NROW, "packed workgroup shape");
+    static_assert((B::NC - 1) * B::CS + 4 * (2 * ZC - 1) * NCW + B::GUARD + 4 * 64 * RW < 65536, "LDS immediate offsets");
+    static constexpr size_t FLAGS = (size_t)B::GUARD + B::CWS; // [guard][NC columns of ring | mirror | pad][flags]
+    static constexpr size_t lds_bytes() { return FLAGS + 4 * (size_t)((NCW + 1 + 3) / 4 * 4); }
+};
+
+// waves per SIMD the register allocation is sized for: what the LDS image lets a CU hold anyway (BG1: 4, i.e. 128 VGPRs), at most 6
+template <int BG, int ZC> constexpr int z64p_wpe() {
+#ifdef NRLDPC_Z64P_WPE
+    return NRLDPC_Z64P_WPE;
+#endif
+    constexpr int by_lds = (int)((160 * 1024) / Z64P<BG, ZC>::lds_bytes()) * 2 * Z64P<BG, ZC>::RW / 4;
+    return by_lds >= 6 ? 6 : by_lds >= 1 ? by_lds : 1;
+}
+
+template <int BG, int ZC, bool ETP>
+__global__ __launch_bounds__(2 * z64p_rw(ZC) * 64, (z64p_wpe<BG, ZC>())) void nrldpc_decode_z64p_kernel(const DecArgs a) {
+    constexpr int NL = BGT<BG>::ROWS;
+    using G = Z64P<BG, ZC>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave / G::RW, lane = tid & 63;
+    const int g = (wave % G::RW) * 64 + lane; // row lane
+    if constexpr (G::NROW < 64 * G::RW) {
+        if (g >= G::NROW) return; // these lanes own no row; barriers count waves, not lanes (no wave is empty: fewer than Z <= 32 retire)
+    }
+    const int z = g / G::NCW, c = g - z * G::NCW;
+    const int cw = blockIdx.x * G::NCW + c;
+    const bool present = cw < a.batch; // the last workgroup of a launch may hold fewer codewords: the others decode zeros
+    int* flags = reinterpret_cast<int*>(lds + G::FLAGS);
+    constexpr size_t ncwz = (size_t)G::COLS * ZC;
+    constexpr bool XF = false;
+    constexpr int V = z64s_variant<BG, ZC, NL>();
+    static_assert((V & SPLIT_DUAL) == 0, "no dual rows in the packed geometry");
+
+    uint32_t R[1] = {(uint32_t)G::GUARD + 4u * (uint32_t)g};
+    const uint32_t RA = R[0] - 4u * (uint32_t)G::NROW, RB = R[0] + 4u * (uint32_t)G::NROW;
+    const size_t base = (size_t)(present ? cw : 0) * ncwz;
+
+    // ---- core columns -> LDS (ring and mirror), the halves take alternate columns; raw bits first, conversions after
+    {
+        auto ingest_as = [&](auto kind_c) {
+            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
+            constexpr int NPU = (G::NC + 1) / 2;
+            uint32_t x[NPU];
+            static_for<NPU>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int col = 2 * k + half;
+                x[k] = 0u;
+                if (present && (2 * k + 1 < G::NC || col < G::NC)) {
+                    if constexpr (F16) x[k] = static_cast<const uint16_t*>(a.llr)[base + (size_t)col * ZC + z];
+                    else x[k] = static_cast<const uint32_t*>(a.llr)[base + (size_t)col * ZC + z];
+                }
+            });
+            static_for<NPU>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int col = 2 * k + half;
+                if (2 * k + 1 < G::NC || col < G::NC) {
+                    float v;
+                    if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)x[k]));
+                    else v = __uint_as_float(x[k]);
+                    const float q = present ? ingest(v, a.scale, true) : 0.0f;
+                    char* home = lds + R[0] + col * G::CS;
+                    *reinterpret_cast<float*>(home) = q;
+                    *reinterpret_cast<float*>(home + 4 * G::NROW) = q;
+                }
+            });
+        };
+        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
+    }
+
+    // hard decisions of this thread's columns of its codeword (the halves take alternate columns) + the iteration count
+    auto write_out = [&](int it) {
+        uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * ZC) + z;
+        static_for<(G::KB + 1) / 2>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const int col = 2 * k + half;
+            if (2 * k + 1 < G::KB || col < G::KB)
+                hard[(size_t)col * ZC] = *reinterpret_cast<const float*>(lds + R[0] + col * G::CS) < 0.0f ? 1 : 0;
+        });
+        if (a.iters && z == 0 && half == 0) a.iters[cw] = it;
+    };
+
+    auto run = [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        using O = Own<BG, NL, H, V>;
+        DecStateS<BG, NL, H, ZC, false, V> st;
+#pragma unroll
+        for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
+#pragma unroll
+        for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
+        auto load_ext = [&](auto kind_c) {
+            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
+            uint32_t xe[O::NEXT > 0 ? O::NEXT : 1];
+            static_for<NL - 4>([&](auto ic) {
+                constexpr int L = 4 + decltype(ic)::value;
+                if constexpr (O::mine(L)) {
+                    constexpr int xi = O::ext_index(L);
+                    const size_t i = base + (size_t)(G::NC + L - 4) * ZC + z;
+                    xe[xi] = 0u;
+                    if (present) {
+                        if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
+                        else xe[xi] = static_cast<const uint32_t*>(a.llr)[i];
+                    }
+                }
+            });
+            static_for<O::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float v;
+                if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)xe[i]));
+                else v = __uint_as_float(xe[i]);
+                st.template set_ext<i>(present ? ingest(v, a.scale, false) : 0.0f);
+            });
+        };
+        if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});
+        else load_ext(std::integral_constant<int, NRLDPC_K_F32>{});
+        __syncthreads(); // the a-posteriori rings are complete
+        const float cap = (127.49f + a.beta) / a.alpha; // see LayerZ64::track3
+        DecArgs av = a;
+        av.beta = 8388608.0f - a.beta;
+#if !NRLDPC_Z64S_RULE_SGPR
+        asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
+#endif
+        uint32_t esign_lo = 0, esign_hi = 0;
+        bool done = !present; // per lane (= per codeword: both halves read the same flags)
+        GroupZ64<BG, ZC, 0, NL, H> g0;
+        if constexpr (H == 0) {
+            g0.template loads<false>(lds, R);
+            g0.template track<false, XF>(st, cap);
+        }
+        for (int it = 1; it <= a.max_iter; ++it) {
+            if constexpr (ETP) { esign_lo = 0; esign_hi = 0; }
+            if constexpr (H == 0) {
+                GroupZ64<BG, ZC, 0, NL, H> nx;
+                s_crit<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, 0, av, cap, esign_lo, esign_hi);
+                g0 = nx;
+            } else {
+                s_early<BG, ZC, NL, H, ETP, XF, 0>(g0, st, lds, R, RA, RB, 0, av, cap, esign_lo, esign_hi);
+            }
+            if constexpr (ETP) {
+                // parity check of this half's rows, per codeword: flags[c] = "codeword c has a violated check",
+                // flags[NCW] = "a codeword that had not converged before still has one"
+                if (tid <= G::NCW) flags[tid] = 0;
+                __syncthreads();
+                uint32_t bad = 0;
+                bool stop = false; // wave-uniform: every lane's codeword is settled (violated, or out of the vote)
+                constexpr auto PO = O::parity_order(); // cheapest rows first
+                static_for<PO.n>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int L = PO.v[i];
+                    if (!stop) {
+                        bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                        if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n || O::ncore(L) > 10 || (i + 1 < PO.n && O::ncore(PO.v[i + 1 < PO.n ? i + 1 : i]) > 10)) {
+                            if (bad && !done) flags[c] = 1;
+                            stop = __all((int)(bad | (uint32_t)done | (uint32_t)__atomic_load_n(&flags[c], __ATOMIC_RELAXED))) != 0;
+                        }
+                    }
+                });
+                if (bad && !done) { flags[c] = 1; flags[G::NCW] = 1; }
+                __syncthreads();
+                if (!done && flags[c] == 0) { // converged at this iteration: its result leaves now
+                    done = true;
+                    write_out(it);
+                }
+                if (__builtin_amdgcn_readfirstlane(flags[G::NCW]) == 0) break; // nobody is left
+            }
+        }
+        if constexpr (!ETP) __syncthreads(); // the last group's writes
+        if (!done) write_out(a.max_iter);
+    };
+    if (half == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
+template <int BG, int ZC, bool ETP> static hipError_t launch_z64p_t(const DecArgs& a, hipStream_t s) {
+    using G = Z64P<BG, ZC>;
+    auto k = nrldpc_decode_z64p_kernel<BG, ZC, ETP>;
+    constexpr size_t lds = G::lds_bytes();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(k, dim3((a.batch + G::NCW - 1) / G::NCW), dim3(G::THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+// every row active, hard output only (the caller checks: anything else is the run-time-Z kernel's)
+template <int BG, int ZC> static hipError_t launch_z64p(const DecArgs& a, hipStream_t s) {
+    return a.early_term ? launch_z64p_t<BG, ZC, true>(a, s) : launch_z64p_t<BG, ZC, false>(a, s);
+}
+
+} // namespace nrldpc
+#endif

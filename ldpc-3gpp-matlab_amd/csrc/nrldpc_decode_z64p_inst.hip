@@ -1,0 +1,19 @@
+// nrldpc_decode_z64p_inst.hip -- one (BG, Z) instantiation of the packed-geometry decoder (nrldpc_decode_z64p.h).
+// build.py compiles this file once per pair of NRLDPC_Z64P_LIST:
+//     hipcc -c -DNRLDPC_Z64_BG=2 -DNRLDPC_Z64_Z=16 nrldpc_decode_z64p_inst.hip -o z64p_2_16.o
+#ifndef NRLDPC_Z64_BG
+#define NRLDPC_Z64_BG 1
+#endif
+#ifndef NRLDPC_Z64_Z
+#define NRLDPC_Z64_Z 32
+#endif
+#include "nrldpc_decode_z64p.h"
+
+#define NRLDPC_CAT_(a, b, c) a##b##_##c
+#define NRLDPC_CAT(a, b, c) NRLDPC_CAT_(a, b, c)
+
+namespace nrldpc {
+hipError_t NRLDPC_CAT(launch_decode_z64p_, NRLDPC_Z64_BG, NRLDPC_Z64_Z)(const DecArgs& a, hipStream_t stream) {
+    return launch_z64p<NRLDPC_Z64_BG, NRLDPC_Z64_Z>(a, stream);
+}
+} // namespace nrldpc

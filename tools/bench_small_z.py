@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Run-time-Z decoder kernel on a sample of the lifting sizes it serves (A/B of kernel builds via NRLDPC_LIB)."""
+"""Decoder kernel time on the small lifting sizes (A/B of kernel builds via NRLDPC_LIB; NRLDPC_FORCE_GENERIC=1 = the run-time-Z
+kernel everywhere; ZS="2 3 4" picks the sizes)."""
 import importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("ldpc-3gpp-matlab_amd")
 DIMS = {1: (46, 68, 22), 2: (42, 52, 10)}
-tag = os.path.basename(os.environ.get("NRLDPC_LIB", "default"))
+tag = os.path.basename(os.environ.get("NRLDPC_LIB", "default")) + (" generic" if os.environ.get("NRLDPC_FORCE_GENERIC") else "")
+ZS = [int(x) for x in os.environ.get("ZS", "2 4 8 16 20 32 36 48 72 80 160").split()]
 for bg in (1, 2):
     rows, cols, kb = DIMS[bg]
-    for Z in (2, 4, 8, 16, 20, 32, 36, 48, 72, 80, 160):
+    for Z in ZS:
         B = max(4096, min(262144, (4096 * 384 // Z) // 256 * 256))
         for et in (0, 1):
             c = pkg.Codec(bg, Z, max_iter=25, early_term=bool(et), llr_dtype=np.float16)
