@@ -327,8 +327,11 @@ bool has_z64_kernel(int bg, int Z) {
     return false;
 }
 
-bool has_z64p_kernel(int bg, int Z) {
+bool has_z64p_kernel(int bg, int Z, bool early_term) {
     if (force_generic_env()) return false;
+#define NRLDPC_Z64P_CASE(b, z) if (!early_term && bg == b && Z == z) return false;
+    NRLDPC_Z64P_ET_ONLY(NRLDPC_Z64P_CASE)
+#undef NRLDPC_Z64P_CASE
 #define NRLDPC_Z64P_CASE(b, z) if (bg == b && Z == z) return true;
     NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE
@@ -337,7 +340,7 @@ bool has_z64p_kernel(int bg, int Z) {
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
     const bool force_generic = force_generic_env();
-    if (!force_generic && !a.app && a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS)) { // the packed builds: all rows, hard output
+    if (!a.app && a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) && has_z64p_kernel(bg, a.Z, a.early_term != 0)) { // the packed builds: all rows, hard output
 #define NRLDPC_Z64P_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64p_##b##_##z(a, stream);
         NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE

@@ -38,7 +38,27 @@
 #define NRLDPC_Z64_DEFER_EXT 0
 #endif
 
+// lane >= T of the executing wave, T a compile-time constant in 1..63: a constant exec mask applied by scalar instructions
+// (s_and_saveexec_b64), no VALU work.  The two halves of the mask are made opaque 32-bit scalars on purpose: as a 64-bit
+// constant the compiler of this ROCm release materialises it with s_mov_b64 and a 32-bit literal both for values that need
+// zero extension (0x00000000ffffffff) and for values that need sign extension (0xfffffffffffffc00); the hardware does one of
+// the two, and the packed kernels decoded wrongly until the halves were separated (tools/dbg_packed.py found it: bit errors
+// after ONE iteration that later iterations mostly repaired -- tests/test_decode_gpu.py::test_packed_kernels_iteration_by_iteration).
+#ifdef NRLDPC_EXP_LANE_CMP
+#define NRLDPC_LANE_GE(T) ((int)(threadIdx.x & 63) >= (T))
+#else
+#define NRLDPC_LANE_GE(T) nrldpc::lane_ge<(T)>()
+#endif
+
 namespace nrldpc {
+
+template <int T> __device__ __forceinline__ bool lane_ge() {
+    static_assert(T >= 1 && T <= 63, "a proper subset of the wave");
+    uint32_t lo = T < 32 ? (~0u << (T & 31)) : 0u, hi = T <= 32 ? ~0u : (~0u << ((T - 32) & 31));
+    asm("" : "+s"(lo));
+    asm("" : "+s"(hi));
+    return __builtin_amdgcn_inverse_ballot_w64(((uint64_t)hi << 32) | lo);
+}
 
 constexpr int z64_set_index(int Z) {
     for (int s = 0; s < 8; ++s)
@@ -47,18 +67,20 @@ constexpr int z64_set_index(int Z) {
     return -1;
 }
 
-// "Packed" geometry (nrldpc_decode_z64p.h): lifting sizes too small to fill a wave with one codeword.  A workgroup's row
-// lanes g = 0 .. Z*NCW-1 (RW waves of 64 per half) carry NCW whole codewords, codeword index fastest: g = z*NCW + c.  A column
-// of the workgroup's LDS image is [ring: Z*NCW words][mirror: the same again][pad: as much again], word u + P*NCW holding ring
-// position (z + P) of codeword c -- consecutive lanes touch consecutive words (no bank conflicts for any Z), the rotation is an
-// instruction immediate exactly as in the block geometry (its "block" is the whole ring: one base address per thread), reads
-// never wrap because the mirror is a full copy, and the twin writes' out-of-range lanes fall into the pad in front (the previous
-// column's; a guard before column 0) or behind.
+// "Packed" geometry (nrldpc_decode_z64p.h): lifting sizes that do not fill waves with one codeword's rows in blocks.  A
+// workgroup's row lanes g = 0 .. Z*NCW-1 (RW waves of 64 per half) carry NCW whole codewords, codeword index fastest:
+// g = z*NCW + c.  A column of the workgroup's LDS image is [ring: Z*NCW words][mirror: the same again], word g + P*NCW holding
+// ring position (z + P) of codeword c -- consecutive lanes touch consecutive words (no bank conflicts for any Z), the rotation
+// is an instruction immediate exactly as in the block geometry (its "block" is the whole ring: one base address per thread),
+// and reads never wrap because the mirror is a full copy.  The twin writes that keep the two copies coherent are owed by
+// every wave here, each by PART of its lanes (the rows whose run wrapped, or the others): the lane sets are compile-time
+// constants per (shift, wave), applied as exec masks by scalar instructions (__builtin_amdgcn_inverse_ballot_w64: s_mov_b64 +
+// s_and_saveexec_b64, no VALU work), so the columns need no guard or pad words between them.
 constexpr bool z64_packed(int Z) {
 #ifdef NRLDPC_Z64_PACK
     return NRLDPC_Z64_PACK != 0;
 #endif
-    return Z <= 32;
+    return Z <= 48 || Z == 56; // = NRLDPC_Z64P_LIST: the sizes with no block-geometry build of either base graph
 }
 // row waves per half of a packed workgroup: one, unless that leaves more than a fifth of the lanes empty and two fill more
 // (Z = 22, 24).  Measured (one session, fixed 25 / parity stop): two-wave halves gain 2-10 % at fixed iterations where they
@@ -144,8 +166,8 @@ template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROW
     static constexpr int NWV = ZC / BLK;                // waves per codeword
     static constexpr int TPC = NWV * 64;                // threads per codeword (lanes BLK..63 of a wave retire)
     static constexpr int PW = PACKED ? z64p_ncw(ZC) : 1; // packed: words between consecutive ring positions (= codewords per workgroup)
-    static constexpr int GUARD = PACKED ? 4 * ZC * PW : 256; // bytes: never-read words in front of every ring (packed: of column 0)
-    static constexpr int CS = PACKED ? 12 * ZC * PW : GUARD + (ZC + 64) * 4; // column stride in bytes (guard + ring + mirror | ring + mirror + pad)
+    static constexpr int GUARD = PACKED ? 4 * ZC * PW : 256; // bytes: never-read words in front of every ring (packed: of column 0 only, so that no address is negative)
+    static constexpr int CS = PACKED ? 8 * ZC * PW : GUARD + (ZC + 64) * 4; // column stride in bytes (guard + ring + mirror | ring + mirror)
     static constexpr int CWS = BGD<BG>::NC * CS;        // codeword stride in bytes (packed: of the workgroup's whole image)
     // a shift P as (index of the thread's base address, byte offset from it)
     static constexpr int ridx(int P) { return P / BLK; }
@@ -429,7 +451,24 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
             constexpr int P = G::shift(e0 + j);
             constexpr int ka = P / G::BLK;
             constexpr int off = G::col(e0 + j) * G::CS + G::roff(P);
-            if constexpr (LayerZ64::owned(j) && ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
+            if constexpr (G::PACKED) {
+                // WV = row wave; lane T of it is the first whose row wrapped into the mirror (ring position z + P >= Z)
+                constexpr int T = (ZC - P) * G::PW - 64 * WV;
+                if constexpr (LayerZ64::owned(j) && G::twin_a(e0 + j, FULL) && T < 64) { // wrapped rows: mirror -> ring
+                    if constexpr (T <= 0) {
+                        *reinterpret_cast<float*>(lds + RA + off) = t[j];
+                    } else {
+                        if (NRLDPC_LANE_GE(T)) *reinterpret_cast<float*>(lds + RA + off) = t[j];
+                    }
+                }
+                if constexpr (LayerZ64::owned(j) && G::twin_b(e0 + j, FULL) && T > 0) { // the other rows: ring -> mirror
+                    if constexpr (T >= 64) {
+                        *reinterpret_cast<float*>(lds + RB + off) = t[j];
+                    } else {
+                        if (!NRLDPC_LANE_GE(T)) *reinterpret_cast<float*>(lds + RB + off) = t[j];
+                    }
+                }
+            } else if constexpr (LayerZ64::owned(j) && ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
                                                  (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV))) {
                 if constexpr (G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV)
                     *reinterpret_cast<float*>(lds + RA + off) = t[j];
@@ -532,8 +571,9 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct Gro
         if constexpr (N > 1) l1.ext(a, esign_lo, esign_hi, nullptr);
         if constexpr (N > 2) l2.ext(a, esign_lo, esign_hi, nullptr);
     }
+    // w: the wave's index within its codeword (block geometry) / its row-wave index (packed geometry)
     __device__ __forceinline__ void twins(char* lds, uint32_t RA, uint32_t RB, int w) const {
-        dispatch_w<0, z64_nwv(ZC)>(w, [&](auto wc) {
+        dispatch_w<0, (z64_packed(ZC) ? z64p_rw(ZC) : z64_nwv(ZC))>(w, [&](auto wc) {
             constexpr int WV = decltype(wc)::value;
             l0.template twins<WV>(lds, RA, RB);
             if constexpr (N > 1) l1.template twins<WV>(lds, RA, RB);

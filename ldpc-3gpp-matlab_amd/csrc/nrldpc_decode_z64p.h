@@ -22,8 +22,8 @@ template <int BG, int ZC> struct Z64P : Z64<BG, ZC, 1, BGT<BG>::ROWS> {
     static constexpr int NROW = ZC * NCW;        // row lanes in use (of 64 RW)
     static constexpr int THREADS = 2 * RW * 64;
     static_assert(NCW >= 1 && NROW <= 64 * RW && NCW + 1 <= NROW, "packed workgroup shape");
-    static_assert((B::NC - 1) * B::CS + 4 * (2 * ZC - 1) * NCW + B::GUARD + 4 * 64 * RW < 65536, "LDS immediate offsets");
-    static constexpr size_t FLAGS = (size_t)B::GUARD + B::CWS; // [guard][NC columns of ring | mirror | pad][flags]
+    static_assert((B::NC - 1) * B::CS + 4 * (2 * ZC - 1) * NCW < 65536, "LDS immediate offsets");
+    static constexpr size_t FLAGS = (size_t)B::GUARD + B::CWS; // [guard][NC columns of ring | mirror][flags]
     static constexpr size_t lds_bytes() { return FLAGS + 4 * (size_t)((NCW + 1 + 3) / 4 * 4); }
 };
 
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(2 * z64p_rw(ZC) * 64, (z64p_wpe<BG, ZC>())) void nr
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave / G::RW, lane = tid & 63;
-    const int g = (wave % G::RW) * 64 + lane; // row lane
+    const int rw = wave % G::RW;         // row wave
+    const int g = rw * 64 + lane;         // row lane
     if constexpr (G::NROW < 64 * G::RW) {
         if (g >= G::NROW) return; // these lanes own no row; barriers count waves, not lanes (no wave is empty: fewer than Z <= 32 retire)
     }
@@ -157,10 +158,10 @@ __global__ __launch_bounds__(2 * z64p_rw(ZC) * 64, (z64p_wpe<BG, ZC>())) void nr
             if constexpr (ETP) { esign_lo = 0; esign_hi = 0; }
             if constexpr (H == 0) {
                 GroupZ64<BG, ZC, 0, NL, H> nx;
-                s_crit<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, 0, av, cap, esign_lo, esign_hi);
+                s_crit<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, rw, av, cap, esign_lo, esign_hi);
                 g0 = nx;
             } else {
-                s_early<BG, ZC, NL, H, ETP, XF, 0>(g0, st, lds, R, RA, RB, 0, av, cap, esign_lo, esign_hi);
+                s_early<BG, ZC, NL, H, ETP, XF, 0>(g0, st, lds, R, RA, RB, rw, av, cap, esign_lo, esign_hi);
             }
             if constexpr (ETP) {
                 // parity check of this half's rows, per codeword: flags[c] = "codeword c has a violated check",
@@ -215,8 +216,16 @@ template <int BG, int ZC, bool ETP> static hipError_t launch_z64p_t(const DecArg
 }
 
 // every row active, hard output only (the caller checks: anything else is the run-time-Z kernel's)
+template <int BG, int ZC> constexpr bool z64p_et_only() {
+#define NRLDPC_Z64P_CASE(b, z) if (BG == b && ZC == z) return true;
+    NRLDPC_Z64P_ET_ONLY(NRLDPC_Z64P_CASE)
+#undef NRLDPC_Z64P_CASE
+    return false;
+}
 template <int BG, int ZC> static hipError_t launch_z64p(const DecArgs& a, hipStream_t s) {
-    return a.early_term ? launch_z64p_t<BG, ZC, true>(a, s) : launch_z64p_t<BG, ZC, false>(a, s);
+    if (a.early_term) return launch_z64p_t<BG, ZC, true>(a, s);
+    if constexpr (z64p_et_only<BG, ZC>()) return hipErrorInvalidValue; // not reached: launch_decode asks has_z64p_kernel first
+    else return launch_z64p_t<BG, ZC, false>(a, s);
 }
 
 } // namespace nrldpc

@@ -54,6 +54,12 @@ template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
     static constexpr bool XL = wgs_per_cu(XOFF + XCHBYTES + XBYTES) == wgs_per_cu(XOFF + XCHBYTES);
     static constexpr size_t XCHOFF = (XOFF + (XL ? XBYTES : 0) + 7) & ~(size_t)7;
     static constexpr size_t lds_bytes() { return XCHOFF + XCHBYTES; }
+    // waves per SIMD the register allocation is sized for: NRLDPC_Z64S_WPE, or fewer where the LDS image holds a CU below that
+    // anyway (BG1 Z = 60, 64: eight 2-wave workgroups = 4 per SIMD, so 128 VGPRs instead of 80 and no scratch)
+    static constexpr int wpe() {
+        const int by_lds = (int)((160 * 1024) / lds_bytes()) * (THREADS / 64) / 4;
+        return by_lds >= NRLDPC_Z64S_WPE ? NRLDPC_Z64S_WPE : by_lds >= 1 ? by_lds : 1;
+    }
 };
 
 template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
@@ -149,7 +155,7 @@ __device__ __forceinline__ void s_dense(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ
 }
 
 template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS>
-__global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, NRLDPC_Z64S_WPE) void nrldpc_decode_z64s_kernel(const DecArgs a) {
+__global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) void nrldpc_decode_z64s_kernel(const DecArgs a) {
     using G = Z64S<BG, ZC, NL>;
     using LGN = LGof<BG, ZC, NL, 0>;
     static_assert(G::usable(), "split kernel: at most 1024 threads");

@@ -51,12 +51,16 @@ NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
 // packed-geometry compile-time-Z builds (nrldpc_decode_z64p.h, nrldpc_decode_z64p_inst.hip): several codewords per wave, the
 // lifting sizes <= 32; every row active and hard output only -- other calls stay with the run-time-Z kernel
 #define NRLDPC_Z64P_LIST(X) \
-    X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 8) X(1, 9) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(1, 15) X(1, 16) X(1, 18) X(1, 20) X(1, 22) X(1, 24) X(1, 26) X(1, 28) X(1, 30) X(1, 32) \
-    X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 7) X(2, 8) X(2, 9) X(2, 10) X(2, 11) X(2, 12) X(2, 13) X(2, 14) X(2, 15) X(2, 16) X(2, 18) X(2, 20) X(2, 22) X(2, 24) X(2, 26) X(2, 28) X(2, 30) X(2, 32)
+    X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 8) X(1, 9) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(1, 15) X(1, 16) X(1, 18) X(1, 20) X(1, 22) X(1, 24) X(1, 26) X(1, 28) X(1, 30) X(1, 32) X(1, 36) X(1, 40) X(1, 44) X(1, 48) X(1, 56) \
+    X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 7) X(2, 8) X(2, 9) X(2, 10) X(2, 11) X(2, 12) X(2, 13) X(2, 14) X(2, 15) X(2, 16) X(2, 18) X(2, 20) X(2, 22) X(2, 24) X(2, 26) X(2, 28) X(2, 30) X(2, 32) X(2, 36) X(2, 40) X(2, 44) X(2, 48) X(2, 56)
+// ... of which these serve the parity-check stop only: at a fixed iteration count the run-time-Z kernel, which fills every
+// lane, is 3-8 % faster there (56-75 % of the lanes filled; with the stop the packed build wins by 17-32 %: its workgroups
+// hold 1-3 codewords and leave when those are done)
+#define NRLDPC_Z64P_ET_ONLY(X) X(1, 36) X(1, 44) X(1, 48) X(2, 44)
 #define NRLDPC_Z64P_DECL(bg, z) hipError_t launch_decode_z64p_##bg##_##z(const DecArgs& a, hipStream_t stream);
 NRLDPC_Z64P_LIST(NRLDPC_Z64P_DECL)
 #undef NRLDPC_Z64P_DECL
-bool has_z64p_kernel(int bg, int Z);
+bool has_z64p_kernel(int bg, int Z, bool early_term);
 // pruned layer counts with software-pipelined builds of their own (one translation unit each): the active-layer counts
 // of BASELINE.json's rate-matching sweep at BG2 Z=384 (R = 1/4 ... 2/3 -> 32, 22, 17, 12, 9, 7 rows; R = 1/5 is all 42),
 // of its BG1 Z=384 R=8/9 shard (5 rows) and of BG1 R = 2/3 and 1/2 (13, 24).  Every other count runs the general kernel.

@@ -51,6 +51,22 @@ def test_every_lifting_size(pkg, orc, bg):
         run_case(pkg, orc, rng, bg, Z, B, 2.0, 6, et=bool(Z & 2), dt=np.float32 if Z % 3 else np.float16)
 
 
+@pytest.mark.parametrize("bg", [1, 2])
+def test_hard_output_kernels_iteration_by_iteration(pkg, orc, bg):
+    """The kernels a hard-output call runs (pipelined row form, split form, packed geometry -- soft output, as in the test above,
+    is always the general kernel's) for every lifting size, at an SNR where the decoder does NOT converge in the iterations
+    given: after 1, 2 and 3 iterations every hard decision must equal the oracle's, so one stale LDS word shows (at a
+    comfortable SNR later iterations repair it and the final decisions agree anyway -- how a wrong exec mask in the packed
+    kernels' twin writes once passed the test above).  Then the parity-check stop: decisions and iteration counts."""
+    rng = np.random.default_rng(4000 + bg)
+    for Z in ALL_Z:
+        B = 2 + int(rng.integers(0, 4)) + (400 // Z if Z < 64 else 0)
+        for iters in (1, 2, 3):
+            run_case(pkg, orc, rng, bg, Z, B, -2.0 if bg == 1 else -3.0, iters, et=False, app=False,
+                     dt=np.float16 if (Z + iters) % 2 else np.float32)
+        run_case(pkg, orc, rng, bg, Z, B, 0.3 if bg == 1 else -0.5, 12, et=True, app=False)
+
+
 @pytest.mark.parametrize("bg,Z,nl,esn0", [(1, 384, 46, -0.8), (1, 384, 5, 6.2), (1, 384, 20, 1.0), (2, 384, 42, -1.0),
                                           (2, 384, 7, 4.5), (2, 384, 22, 0.5), (1, 352, 30, 0.0), (2, 208, 21, 1.0),
                                           (1, 64, 4, 8.0), (2, 20, 12, 2.0),
