@@ -328,9 +328,10 @@ bool has_z64_kernel(int bg, int Z) {
 }
 
 bool has_z64p_kernel(int bg, int Z, bool early_term) {
-    if (force_generic_env()) return false;
-#define NRLDPC_Z64P_CASE(b, z) if (!early_term && bg == b && Z == z) return false;
-    NRLDPC_Z64P_ET_ONLY(NRLDPC_Z64P_CASE)
+    static const bool no_packed = getenv("NRLDPC_NO_PACKED") != nullptr; // A/B against the block-geometry / run-time-Z kernels
+    if (force_generic_env() || no_packed) return false;
+#define NRLDPC_Z64P_CASE(b, z) if (early_term && bg == b && Z == z) return false;
+    NRLDPC_Z64P_NOT_ET(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE
 #define NRLDPC_Z64P_CASE(b, z) if (bg == b && Z == z) return true;
     NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)

@@ -76,24 +76,37 @@ constexpr int z64_set_index(int Z) {
 // every wave here, each by PART of its lanes (the rows whose run wrapped, or the others): the lane sets are compile-time
 // constants per (shift, wave), applied as exec masks by scalar instructions (__builtin_amdgcn_inverse_ballot_w64: s_mov_b64 +
 // s_and_saveexec_b64, no VALU work), so the columns need no guard or pad words between them.
-constexpr bool z64_packed(int Z) {
+// The geometry is a property of the translation unit: nrldpc_decode_z64p_inst.hip defines NRLDPC_Z64_PACK, the block-geometry
+// units do not, so one (BG, Z) can have builds in both (nrldpc_decode.hip: the packed one serves hard-output calls with every
+// row active where it is the faster, NRLDPC_Z64P_LIST; pruned rows / soft output stay with the block or run-time-Z kernels).
+constexpr bool z64_packed(int) {
 #ifdef NRLDPC_Z64_PACK
     return NRLDPC_Z64_PACK != 0;
+#else
+    return false;
 #endif
-    return Z <= 48 || Z == 56; // = NRLDPC_Z64P_LIST: the sizes with no block-geometry build of either base graph
 }
-// row waves per half of a packed workgroup: one, unless that leaves more than a fifth of the lanes empty and two fill more
-// (Z = 22, 24).  Measured (one session, fixed 25 / parity stop): two-wave halves gain 2-10 % at fixed iterations where they
+// Row waves per half of a packed workgroup: 1, 2 or 4 -- the first of these that fills 80 % of its lanes, else the best filled.
+// Measured (one session each, fixed 25 / parity stop): for Z <= 32 two-wave halves gain 2-10 % at fixed iterations where they
 // fill more lanes but lose 10-25 % with the parity stop on BG1 (a workgroup lives until its last codeword converges, and
-// holds twice as many); three-wave halves (6-wave workgroups, three per CU) lose 14-48 %.
-constexpr int z64p_rw(int Z) {
+// holds twice as many), so there two waves are taken only below 80 % (Z = 22, 24); three-wave halves (6-wave workgroups: 2 + 2
+// + 1 + 1 waves on the four SIMDs) lose 14-48 % everywhere; four-wave halves are fine (Z = 72, 80); five and more (BG2 Z = 52
+// ... 352 with 6-8 codewords or 10-16 waves per workgroup) lose to the block geometry.  BG1's last column would also lie
+// beyond the 64 KB an LDS instruction's immediate offset reaches with more than 4.
+constexpr int z64p_rw(int BG, int Z) {
 #ifdef NRLDPC_Z64P_RW
     return NRLDPC_Z64P_RW;
 #endif
-    const int f1 = (64 / Z) * Z, f2 = (128 / Z) * Z;
-    return (f1 * 5 < 64 * 4 && f2 > 2 * f1) ? 2 : 1;
+    (void)BG;
+    int best = 1, fill = -1;
+    for (int rw = 1; rw <= 4; rw *= 2) {
+        const int f = (64 * rw / Z) * Z * 1000 / (64 * rw);
+        if (f >= 800) return rw;
+        if (f > fill) { fill = f; best = rw; }
+    }
+    return best;
 }
-constexpr int z64p_ncw(int Z) { return 64 * z64p_rw(Z) / Z; } // codewords per packed workgroup
+constexpr int z64p_ncw(int BG, int Z) { return 64 * z64p_rw(BG, Z) / Z; } // codewords per packed workgroup
 
 // Rows per wave ("block"): 64 when 64 | Z, else the largest divisor of Z below 64 that is a multiple of 4.
 // A wave then owns B consecutive rows and its lanes B..63 retire at kernel entry (Z = 240 -> 4 waves of 60
@@ -165,7 +178,7 @@ template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROW
     static_assert(BLK >= (PACKED ? 2 : 4) && ZC % BLK == 0, "no usable block size for this lifting size");
     static constexpr int NWV = ZC / BLK;                // waves per codeword
     static constexpr int TPC = NWV * 64;                // threads per codeword (lanes BLK..63 of a wave retire)
-    static constexpr int PW = PACKED ? z64p_ncw(ZC) : 1; // packed: words between consecutive ring positions (= codewords per workgroup)
+    static constexpr int PW = PACKED ? z64p_ncw(BG, ZC) : 1; // packed: words between consecutive ring positions (= codewords per workgroup)
     static constexpr int GUARD = PACKED ? 4 * ZC * PW : 256; // bytes: never-read words in front of every ring (packed: of column 0 only, so that no address is negative)
     static constexpr int CS = PACKED ? 8 * ZC * PW : GUARD + (ZC + 64) * 4; // column stride in bytes (guard + ring + mirror | ring + mirror)
     static constexpr int CWS = BGD<BG>::NC * CS;        // codeword stride in bytes (packed: of the workgroup's whole image)
@@ -573,7 +586,7 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct Gro
     }
     // w: the wave's index within its codeword (block geometry) / its row-wave index (packed geometry)
     __device__ __forceinline__ void twins(char* lds, uint32_t RA, uint32_t RB, int w) const {
-        dispatch_w<0, (z64_packed(ZC) ? z64p_rw(ZC) : z64_nwv(ZC))>(w, [&](auto wc) {
+        dispatch_w<0, (z64_packed(ZC) ? z64p_rw(BG, ZC) : z64_nwv(ZC))>(w, [&](auto wc) {
             constexpr int WV = decltype(wc)::value;
             l0.template twins<WV>(lds, RA, RB);
             if constexpr (N > 1) l1.template twins<WV>(lds, RA, RB);

@@ -17,11 +17,11 @@ namespace nrldpc {
 template <int BG, int ZC> struct Z64P : Z64<BG, ZC, 1, BGT<BG>::ROWS> {
     using B = Z64<BG, ZC, 1, BGT<BG>::ROWS>;
     static_assert(B::PACKED && B::NWV == 1, "packed geometry");
-    static constexpr int RW = z64p_rw(ZC);       // row waves per half
-    static constexpr int NCW = z64p_ncw(ZC);     // codewords per workgroup
+    static constexpr int RW = z64p_rw(BG, ZC);       // row waves per half
+    static constexpr int NCW = z64p_ncw(BG, ZC);     // codewords per workgroup
     static constexpr int NROW = ZC * NCW;        // row lanes in use (of 64 RW)
     static constexpr int THREADS = 2 * RW * 64;
-    static_assert(NCW >= 1 && NROW <= 64 * RW && NCW + 1 <= NROW, "packed workgroup shape");
+    static_assert(NCW >= 1 && NROW <= 64 * RW && 64 * RW - NROW < 64 && NCW + 1 <= NROW && 2 * RW <= 16, "packed workgroup shape");
     static_assert((B::NC - 1) * B::CS + 4 * (2 * ZC - 1) * NCW < 65536, "LDS immediate offsets");
     static constexpr size_t FLAGS = (size_t)B::GUARD + B::CWS; // [guard][NC columns of ring | mirror][flags]
     static constexpr size_t lds_bytes() { return FLAGS + 4 * (size_t)((NCW + 1 + 3) / 4 * 4); }
@@ -37,7 +37,7 @@ template <int BG, int ZC> constexpr int z64p_wpe() {
 }
 
 template <int BG, int ZC, bool ETP>
-__global__ __launch_bounds__(2 * z64p_rw(ZC) * 64, (z64p_wpe<BG, ZC>())) void nrldpc_decode_z64p_kernel(const DecArgs a) {
+__global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC>())) void nrldpc_decode_z64p_kernel(const DecArgs a) {
     constexpr int NL = BGT<BG>::ROWS;
     using G = Z64P<BG, ZC>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(2 * z64p_rw(ZC) * 64, (z64p_wpe<BG, ZC>())) void nr
     const int rw = wave % G::RW;         // row wave
     const int g = rw * 64 + lane;         // row lane
     if constexpr (G::NROW < 64 * G::RW) {
-        if (g >= G::NROW) return; // these lanes own no row; barriers count waves, not lanes (no wave is empty: fewer than Z <= 32 retire)
+        if (g >= G::NROW) return; // these lanes own no row; barriers count waves, not lanes (no wave is empty: fewer than Z lanes retire, and the shape rule keeps that below 64)
     }
     const int z = g / G::NCW, c = g - z * G::NCW;
     const int cw = blockIdx.x * G::NCW + c;
@@ -216,16 +216,16 @@ template <int BG, int ZC, bool ETP> static hipError_t launch_z64p_t(const DecArg
 }
 
 // every row active, hard output only (the caller checks: anything else is the run-time-Z kernel's)
-template <int BG, int ZC> constexpr bool z64p_et_only() {
+template <int BG, int ZC> constexpr bool z64p_not_et() {
 #define NRLDPC_Z64P_CASE(b, z) if (BG == b && ZC == z) return true;
-    NRLDPC_Z64P_ET_ONLY(NRLDPC_Z64P_CASE)
+    NRLDPC_Z64P_NOT_ET(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE
     return false;
 }
 template <int BG, int ZC> static hipError_t launch_z64p(const DecArgs& a, hipStream_t s) {
-    if (a.early_term) return launch_z64p_t<BG, ZC, true>(a, s);
-    if constexpr (z64p_et_only<BG, ZC>()) return hipErrorInvalidValue; // not reached: launch_decode asks has_z64p_kernel first
-    else return launch_z64p_t<BG, ZC, false>(a, s);
+    if (!a.early_term) return launch_z64p_t<BG, ZC, false>(a, s);
+    if constexpr (z64p_not_et<BG, ZC>()) return hipErrorInvalidValue; // not reached: launch_decode asks has_z64p_kernel first
+    else return launch_z64p_t<BG, ZC, true>(a, s);
 }
 
 } // namespace nrldpc

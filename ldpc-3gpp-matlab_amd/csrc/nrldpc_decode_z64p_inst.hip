@@ -7,6 +7,7 @@
 #ifndef NRLDPC_Z64_Z
 #define NRLDPC_Z64_Z 32
 #endif
+#define NRLDPC_Z64_PACK 1 // the geometry of this unit (z64_packed, nrldpc_decode_z64.h)
 #include "nrldpc_decode_z64p.h"
 
 #define NRLDPC_CAT_(a, b, c) a##b##_##c

@@ -1,7 +1,5 @@
-cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out; OUT=gpurun_out/exp_pk2.log; : > $OUT
-for bg in 1 2; do for z in 36 40 44 48 56; do
-  python tools/exp_check.py $bg $z 2>&1 | grep -E "Gbit|FAIL|Error|error" | tee -a $OUT
-  NRLDPC_FORCE_GENERIC=1 python tools/exp_check.py $bg $z 2>&1 | grep -E "Gbit|FAIL|Error|error" | sed 's/^default/generic/' | tee -a $OUT
-  l=exp_libs/lib_${bg}_${z}_0_0_rw3.so
-  [ -f $l ] && NRLDPC_LIB=$PWD/$l python tools/exp_check.py $bg $z 2>&1 | grep -E "Gbit|FAIL|Error|error" | tee -a $OUT
-done; done
+cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out; OUT=gpurun_out/exp_pk4.log; : > $OUT
+run() { python tools/exp_check.py $1 $2 2>&1 | grep -E "Gbit|FAIL|Error|error" | tee -a $OUT
+  NRLDPC_NO_PACKED=1 python tools/exp_check.py $1 $2 2>&1 | grep -E "Gbit|FAIL|Error|error" | sed 's/^default/nopack /' | tee -a $OUT; }
+for z in 36 44 48; do run 1 $z; done
+for z in 36 44 48 52 56 72 80; do run 2 $z; done
