@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Extended differential fuzz of the decoder kernels against the CPU oracle (the test-suite version runs 60
-cases; this runs N, default 600, biased towards the compile-time-Z sizes).  python tools/fuzz_decode.py [N] [seed]"""
+cases; this runs N, default 600, biased towards the compile-time-Z sizes).  python tools/fuzz_decode.py [N] [seed]
+SMALL=1: biased towards the packed-geometry sizes (Z <= 80), every row active, hard output, ragged batches of up to 70 codewords."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,15 @@ T = importlib.import_module("test_decode_gpu")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 BIG = [z for z in ALL_Z if z >= 52]
+SMALL = [z for z in ALL_Z if z <= 80] if os.environ.get("SMALL") else None
 for i in range(N):
+    if SMALL and rng.random() < 0.85:
+        bg = int(rng.integers(1, 3)); Z = int(rng.choice(SMALL))
+        T.run_case(pkg, orc, rng, bg, Z, int(rng.integers(1, 1 + max(8, min(70, 600 // Z)))), float(rng.uniform(-3.0, 5.0)), int(rng.integers(1, 13)),
+                   nl=0, et=bool(rng.integers(0, 2)), dt=[np.float16, np.float32][int(rng.integers(0, 2))], app=False)
+        if i % 50 == 49:
+            print(i + 1, "cases ok", flush=True)
+        continue
     bg = int(rng.integers(1, 3))
     Z = int(rng.choice(BIG)) if rng.random() < 0.75 else int(rng.choice(ALL_Z))
     rows = BG_DIMS[bg][0]
