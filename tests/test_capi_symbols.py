@@ -158,3 +158,27 @@ def test_committed_profile_belongs_to_the_tree_kernels(pkg):
     line = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line.json")))
     assert line["roofline"]["profile"]["nrldpc_kernel_id"] == kid and line["roofline"]["frac"] is not None
     assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] == "valu_issue"
+
+
+def test_kernel_lists_of_the_build_and_of_the_dispatch_agree():
+    """build.py compiles one translation unit per (BG, Z[, layers]) of nrldpc_kernels.h's X-macro lists, which are also what
+    nrldpc_decode.hip dispatches on: the two must name the same pairs (a missing unit is a link error, a superfluous one dead
+    code), and the packed-geometry exceptions must be members of the packed list."""
+    import importlib
+    bld = importlib.import_module("ldpc-3gpp-matlab_amd.build")
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldpc-3gpp-matlab_amd", "csrc",
+                            "nrldpc_kernels.h")).read().replace("\\\n", " ")
+
+    def pairs(name):
+        m = re.search(r"#define %s\(X\)([^\n]*)" % name, src)
+        assert m, name
+        return [tuple(int(x) for x in t.split(",")) for t in re.findall(r"X\(([^)]*)\)", m.group(1))]
+
+    assert sorted(pairs("NRLDPC_Z64_LIST")) == sorted(bld.Z64_PAIRS)
+    assert sorted(pairs("NRLDPC_Z64P_LIST")) == sorted(bld.Z64P_PAIRS)
+    assert sorted(pairs("NRLDPC_Z64_NL_LIST")) == sorted(bld.Z64_NL)
+    assert set(pairs("NRLDPC_Z64P_NOT_ET")) <= set(bld.Z64P_PAIRS)
+    # a packed size that has no block-geometry unit falls back to the run-time-Z kernel for pruned rows / soft output: fine;
+    # but every lifting size of TS 38.212 must be a legal Z for it
+    all_z = sorted(a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384)
+    assert all(z in all_z for _, z in bld.Z64_PAIRS + bld.Z64P_PAIRS)

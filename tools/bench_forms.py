@@ -2,7 +2,8 @@
 """Row form against split form for every compile-time-Z size, in ONE GPU session: run once per form with the A/B library
 (NRLDPC_BUILD_AB=1 build; NRLDPC_LIB=.../libnrldpc_hip_ab.so NRLDPC_SPLIT=0|1 OUT_SUFFIX=_row|_split).  Per size: 25 fixed
 iterations and the parity-check stop on noisy codewords at the waterfall point, all layers, fp16 LLRs resident in HBM.
-Writes gpurun_out/bench_forms<OUT_SUFFIX>.json -- the evidence behind z64_split_default (nrldpc_decode_z64.h)."""
+Writes gpurun_out/bench_forms<OUT_SUFFIX>.json -- the evidence behind z64_split_default (nrldpc_decode_z64.h).
+PAIRS=packed: the packed-geometry sizes instead (run with and without NRLDPC_NO_PACKED=1: the evidence behind NRLDPC_Z64P_LIST)."""
 import importlib, json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +12,7 @@ pkg = importlib.import_module("ldpc-3gpp-matlab_amd")
 bld = importlib.import_module("ldpc-3gpp-matlab_amd.build")
 DIMS = {1: (46, 68, 22), 2: (42, 52, 10)}
 out = []
-for bg, Z in bld.Z64_PAIRS:
+for bg, Z in (bld.Z64P_PAIRS if os.environ.get("PAIRS") == "packed" else bld.Z64_PAIRS):
     rows, cols, kb = DIMS[bg]
     B = max(4096, (4096 * 384 // Z) // 256 * 256)
     esn0 = -0.5 if bg == 1 else -1.0
