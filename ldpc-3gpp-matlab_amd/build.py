@@ -29,6 +29,8 @@ Z64_PAIRS = [(1, z) for z in Z64_BG1] + [(2, z) for z in Z64_BG2]
 Z64P_BG1 = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52, 56, 72, 80)
 Z64P_BG2 = Z64P_BG1
 Z64P_PAIRS = [(1, z) for z in Z64P_BG1] + [(2, z) for z in Z64P_BG2]
+# = NRLDPC_Z64P_NL_LIST: (BG, Z, active layers) with packed builds of their own
+Z64P_NL = [(2, 20, 12)]
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7)]
 HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h"]
@@ -104,6 +106,8 @@ def build_lib(force=False, verbose=False, jobs=None):
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64_PAIRS]
     units += [(os.path.join(CSRC, Z64P_SOURCE), os.path.join(OBJDIR, "z64p_%d_%d.o" % (bg, z)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64P_PAIRS]
+    units += [(os.path.join(CSRC, Z64P_SOURCE), os.path.join(OBJDIR, "z64p_%d_%d_nl%d.o" % (bg, z, nl)),
+               ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64P_NL]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64_NL]
     # An object is reused only when it was compiled from exactly these inputs: contents of its source and of every

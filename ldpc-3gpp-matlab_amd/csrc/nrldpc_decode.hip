@@ -341,6 +341,12 @@ bool has_z64p_kernel(int bg, int Z, bool early_term) {
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
     const bool force_generic = force_generic_env();
+    static const bool no_packed = getenv("NRLDPC_NO_PACKED") != nullptr;
+    if (!force_generic && !no_packed && !a.app) { // pruned layer counts with packed builds of their own
+#define NRLDPC_Z64P_NL_CASE(b, z, nl) if (bg == b && a.Z == z && a.n_layers == nl) return launch_decode_z64p_##b##_##z##_nl##nl(a, stream);
+        NRLDPC_Z64P_NL_LIST(NRLDPC_Z64P_NL_CASE)
+#undef NRLDPC_Z64P_NL_CASE
+    }
     if (!a.app && a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) && has_z64p_kernel(bg, a.Z, a.early_term != 0)) { // the packed builds: all rows, hard output
 #define NRLDPC_Z64P_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64p_##b##_##z(a, stream);
         NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)

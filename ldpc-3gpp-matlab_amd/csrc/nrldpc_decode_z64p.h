@@ -14,8 +14,8 @@
 
 namespace nrldpc {
 
-template <int BG, int ZC> struct Z64P : Z64<BG, ZC, 1, BGT<BG>::ROWS> {
-    using B = Z64<BG, ZC, 1, BGT<BG>::ROWS>;
+template <int BG, int ZC, int NL = BGT<BG>::ROWS> struct Z64P : Z64<BG, ZC, 1, NL> {
+    using B = Z64<BG, ZC, 1, NL>;
     static_assert(B::PACKED && B::NWV == 1, "packed geometry");
     static constexpr int RW = z64p_rw(BG, ZC);       // row waves per half
     static constexpr int NCW = z64p_ncw(BG, ZC);     // codewords per workgroup
@@ -28,18 +28,18 @@ template <int BG, int ZC> struct Z64P : Z64<BG, ZC, 1, BGT<BG>::ROWS> {
 };
 
 // waves per SIMD the register allocation is sized for: what the LDS image lets a CU hold anyway (BG1: 4, i.e. 128 VGPRs), at most 6
-template <int BG, int ZC> constexpr int z64p_wpe() {
+template <int BG, int ZC, int NL> constexpr int z64p_wpe() {
 #ifdef NRLDPC_Z64P_WPE
     return NRLDPC_Z64P_WPE;
 #endif
-    constexpr int by_lds = (int)((160 * 1024) / Z64P<BG, ZC>::lds_bytes()) * 2 * Z64P<BG, ZC>::RW / 4;
+    constexpr int by_lds = (int)((160 * 1024) / Z64P<BG, ZC, NL>::lds_bytes()) * 2 * Z64P<BG, ZC, NL>::RW / 4;
     return by_lds >= 6 ? 6 : by_lds >= 1 ? by_lds : 1;
 }
 
-template <int BG, int ZC, bool ETP>
-__global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC>())) void nrldpc_decode_z64p_kernel(const DecArgs a) {
-    constexpr int NL = BGT<BG>::ROWS;
-    using G = Z64P<BG, ZC>;
+// NL: the active rows 0..NL-1, a compile-time fact (all rows, or one of the pruned counts of NRLDPC_Z64P_NL_LIST)
+template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS>
+__global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>())) void nrldpc_decode_z64p_kernel(const DecArgs a) {
+    using G = Z64P<BG, ZC, NL>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC>())) voi
     else run(std::integral_constant<int, 1>{});
 }
 
-template <int BG, int ZC, bool ETP> static hipError_t launch_z64p_t(const DecArgs& a, hipStream_t s) {
-    using G = Z64P<BG, ZC>;
-    auto k = nrldpc_decode_z64p_kernel<BG, ZC, ETP>;
+template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t launch_z64p_t(const DecArgs& a, hipStream_t s) {
+    using G = Z64P<BG, ZC, NL>;
+    auto k = nrldpc_decode_z64p_kernel<BG, ZC, ETP, NL>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {};
@@ -215,12 +215,16 @@ template <int BG, int ZC, bool ETP> static hipError_t launch_z64p_t(const DecArg
     return hipGetLastError();
 }
 
-// every row active, hard output only (the caller checks: anything else is the run-time-Z kernel's)
+// hard output only, every row active or the layer count of the build (the caller checks: anything else is the run-time-Z kernel's)
 template <int BG, int ZC> constexpr bool z64p_not_et() {
 #define NRLDPC_Z64P_CASE(b, z) if (BG == b && ZC == z) return true;
     NRLDPC_Z64P_NOT_ET(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE
     return false;
+}
+// a pruned layer count with builds of its own (NRLDPC_Z64P_NL_LIST)
+template <int BG, int ZC, int NL> static hipError_t launch_z64p_pruned(const DecArgs& a, hipStream_t s) {
+    return a.early_term ? launch_z64p_t<BG, ZC, true, NL>(a, s) : launch_z64p_t<BG, ZC, false, NL>(a, s);
 }
 template <int BG, int ZC> static hipError_t launch_z64p(const DecArgs& a, hipStream_t s) {
     if (!a.early_term) return launch_z64p_t<BG, ZC, false>(a, s);

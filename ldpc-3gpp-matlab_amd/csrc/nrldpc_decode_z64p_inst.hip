@@ -14,7 +14,16 @@
 #define NRLDPC_CAT(a, b, c) NRLDPC_CAT_(a, b, c)
 
 namespace nrldpc {
+#ifdef NRLDPC_Z64_NL
+// -DNRLDPC_Z64_NL=<count>: the builds of one pruned layer count (NRLDPC_Z64P_NL_LIST)
+#define NRLDPC_CAT4_(a, b, c, d) a##b##_##c##_nl##d
+#define NRLDPC_CAT4(a, b, c, d) NRLDPC_CAT4_(a, b, c, d)
+hipError_t NRLDPC_CAT4(launch_decode_z64p_, NRLDPC_Z64_BG, NRLDPC_Z64_Z, NRLDPC_Z64_NL)(const DecArgs& a, hipStream_t stream) {
+    return launch_z64p_pruned<NRLDPC_Z64_BG, NRLDPC_Z64_Z, NRLDPC_Z64_NL>(a, stream);
+}
+#else
 hipError_t NRLDPC_CAT(launch_decode_z64p_, NRLDPC_Z64_BG, NRLDPC_Z64_Z)(const DecArgs& a, hipStream_t stream) {
     return launch_z64p<NRLDPC_Z64_BG, NRLDPC_Z64_Z>(a, stream);
 }
+#endif
 } // namespace nrldpc

@@ -60,6 +60,12 @@ NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
 NRLDPC_Z64P_LIST(NRLDPC_Z64P_DECL)
 #undef NRLDPC_Z64P_DECL
 bool has_z64p_kernel(int bg, int Z, bool early_term);
+// ... and pruned layer counts with packed builds of their own: BASELINE.json configs[0] (BG2, A = 100, R = 1/3: Z = 20, 12 rows),
+// the operating point of the reference's plot_BLER_vs_SNR.m defaults
+#define NRLDPC_Z64P_NL_LIST(X) X(2, 20, 12)
+#define NRLDPC_Z64P_NL_DECL(bg, z, nl) hipError_t launch_decode_z64p_##bg##_##z##_nl##nl(const DecArgs& a, hipStream_t stream);
+NRLDPC_Z64P_NL_LIST(NRLDPC_Z64P_NL_DECL)
+#undef NRLDPC_Z64P_NL_DECL
 // pruned layer counts with software-pipelined builds of their own (one translation unit each): the active-layer counts
 // of BASELINE.json's rate-matching sweep at BG2 Z=384 (R = 1/4 ... 2/3 -> 32, 22, 17, 12, 9, 7 rows; R = 1/5 is all 42),
 // of its BG1 Z=384 R=8/9 shard (5 rows) and of BG1 R = 2/3 and 1/2 (13, 24).  Every other count runs the general kernel.

@@ -65,6 +65,10 @@ def test_hard_output_kernels_iteration_by_iteration(pkg, orc, bg):
             run_case(pkg, orc, rng, bg, Z, B, -2.0 if bg == 1 else -3.0, iters, et=False, app=False,
                      dt=np.float16 if (Z + iters) % 2 else np.float32)
         run_case(pkg, orc, rng, bg, Z, B, 0.3 if bg == 1 else -0.5, 12, et=True, app=False)
+    if bg == 2:  # NRLDPC_Z64P_NL_LIST: a pruned layer count with packed builds of its own (BASELINE configs[0]: Z = 20, 12 rows)
+        for iters in (1, 2, 3):
+            run_case(pkg, orc, rng, 2, 20, 37, 1.0, iters, nl=12, et=False, app=False)
+        run_case(pkg, orc, rng, 2, 20, 37, 3.0, 12, nl=12, et=True, app=False)
 
 
 @pytest.mark.parametrize("bg,Z,nl,esn0", [(1, 384, 46, -0.8), (1, 384, 5, 6.2), (1, 384, 20, 1.0), (2, 384, 42, -1.0),
