@@ -352,6 +352,14 @@ hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes
         NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE
     }
+    static const bool no_packed_general = getenv("NRLDPC_NO_PACKED_GENERAL") != nullptr; // A/B against the run-time-Z kernel
+    if (bg == 2 && !force_generic && !no_packed && !no_packed_general && !has_z64_kernel(bg, a.Z)) {
+        // the packed geometry's general kernel: any layer count, soft output -- BG2 (nrldpc_decode_z64p.h: z64pg_serves); sizes
+        // with a block-geometry build keep that one's
+#define NRLDPC_Z64P_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64pg_##b##_##z(a, stream);
+        NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
+#undef NRLDPC_Z64P_CASE
+    }
 #define NRLDPC_Z64_CASE(b, z) if (!force_generic && bg == b && a.Z == z) return launch_decode_z64_##b##_##z(a, stream);
     NRLDPC_Z64_LIST(NRLDPC_Z64_CASE)
 #undef NRLDPC_Z64_CASE

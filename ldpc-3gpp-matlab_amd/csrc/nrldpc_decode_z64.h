@@ -518,7 +518,7 @@ __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uin
                                           uint32_t& esign_hi, float* app_ext) {
     constexpr int N = GE - GS + 1;
     static_assert(N >= 1 && N <= 3, "group size");
-    constexpr int NWV = z64_nwv(ZC);
+    constexpr int NWV = z64_packed(ZC) ? z64p_rw(BG, ZC) : z64_nwv(ZC); // packed geometry: w is the row-wave index
     LayerZ64<BG, ZC, GS, FULL> l0;
     LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), FULL> l1;
     LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), FULL> l2;

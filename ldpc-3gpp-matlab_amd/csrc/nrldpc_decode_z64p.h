@@ -215,6 +215,180 @@ template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t la
     return hipGetLastError();
 }
 
+
+// ---- the general kernel of the packed geometry: one thread per check row, run-time layer count, soft output ------------------
+// What the pipelined builds above do not serve (pruned rows other than NRLDPC_Z64P_NL_LIST, per-iteration soft values): the
+// unpipelined layer loop of the block geometry's general kernel (group_z64 with both twin writes, one barrier per group) on
+// the packed LDS image.  A workgroup is RW waves holding the same NCW codewords.  Early termination as above: nothing is
+// frozen; a codeword's outputs leave at the iteration it converges, and its soft-output stores stop there.
+// Measured against the run-time-Z kernel it would replace (tools/exp_check.py with a layer count, one session): BG2 +1...+34 %
+// (Z = 8 / 20 / 32: +34 / +12 / +20 %; Z = 56, 80: -5...+1 % fixed, +2...+19 % with the parity stop); BG1 -3...-17 %: one thread
+// per row keeps all 80 message registers (142-161 VGPRs) and the doubled rings allow only 11 waves per CU, three per SIMD,
+// where the run-time-Z kernel runs four.  So BG2 only.
+template <int BG> constexpr bool z64pg_serves() { return BG == 2; }
+
+template <int BG, int ZC> constexpr int z64pg_wpe() {
+    constexpr int by_lds = (int)((160 * 1024) / Z64P<BG, ZC>::lds_bytes()) * Z64P<BG, ZC>::RW / 4;
+    constexpr int cap = BG == 2 ? 6 : 4;
+    return by_lds >= cap ? cap : by_lds >= 1 ? by_lds : 1;
+}
+
+template <int BG, int ZC>
+__global__ __launch_bounds__(z64p_rw(BG, ZC) * 64, (z64pg_wpe<BG, ZC>())) void nrldpc_decode_z64pg_kernel(const DecArgs a) {
+    using G = Z64P<BG, ZC>;
+    using LG = LayerGroups<BG>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int rw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = tid; // row lane (one thread per row: no halves)
+    if constexpr (G::NROW < 64 * G::RW) {
+        if (g >= G::NROW) return;
+    }
+    const int z = g / G::NCW, c = g - z * G::NCW;
+    const int cw = blockIdx.x * G::NCW + c;
+    const bool present = cw < a.batch;
+    int* flags = reinterpret_cast<int*>(lds + G::FLAGS);
+    constexpr size_t ncwz = (size_t)G::COLS * ZC;
+    uint32_t R[1] = {(uint32_t)G::GUARD + 4u * (uint32_t)g};
+    const uint32_t RA = R[0] - 4u * (uint32_t)G::NROW, RB = R[0] + 4u * (uint32_t)G::NROW;
+    const size_t base = (size_t)(present ? cw : 0) * ncwz;
+    float* app_row = (present && a.app) ? a.app + base + z : nullptr;
+
+    DecState<BG> st;
+#pragma unroll
+    for (int i = 0; i < G::NW; ++i) st.rm[i] = 0;
+#pragma unroll
+    for (int i = 0; i < G::NXW; ++i) st.xq[i] = 0;
+    {   // all loads of a thread as raw bits first, conversions after (see the block geometry's prologue)
+        const int next_used = a.app ? G::NEXT : launder(a.n_layers) - 4; // a pruned row's extension LLR is never used
+        auto ingest_as = [&](auto kind_c) {
+            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
+            auto raw = [&](size_t i) -> uint32_t {
+                if (!present) return 0u;
+                if constexpr (F16) return static_cast<const uint16_t*>(a.llr)[i];
+                else return static_cast<const uint32_t*>(a.llr)[i];
+            };
+            auto val = [&](uint32_t r) -> float {
+                if constexpr (F16) return __half2float(__ushort_as_half((unsigned short)r));
+                else return __uint_as_float(r);
+            };
+            uint32_t x[G::NC], xe[G::NEXT];
+            static_for<G::NC>([&](auto cc) {
+                constexpr int col = decltype(cc)::value;
+                x[col] = raw(base + (size_t)col * ZC + z);
+            });
+            static_for<(G::NEXT + 7) / 8>([&](auto bc) {
+                constexpr int i0 = decltype(bc)::value * 8;
+                constexpr int i1 = i0 + 8 < G::NEXT ? i0 + 8 : G::NEXT;
+                if (i0 < next_used) {
+                    static_for<i1 - i0>([&](auto ic) {
+                        constexpr int i = i0 + decltype(ic)::value;
+                        xe[i] = raw(base + (size_t)(G::NC + i) * ZC + z);
+                    });
+                } else {
+                    static_for<i1 - i0>([&](auto ic) { xe[i0 + decltype(ic)::value] = 0u; });
+                }
+            });
+            static_for<G::NC>([&](auto cc) {
+                constexpr int col = decltype(cc)::value;
+                const float q = present ? ingest(val(x[col]), a.scale, true) : 0.0f;
+                char* home = lds + R[0] + col * G::CS;
+                *reinterpret_cast<float*>(home) = q;
+                *reinterpret_cast<float*>(home + 4 * G::NROW) = q;
+            });
+            static_for<G::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                f32_to_byte<i & 3>(st.xq[i >> 2], present ? ingest(val(xe[i]), a.scale, false) : 0.0f);
+            });
+        };
+        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
+        if (app_row) { // soft output of columns whose layer is inactive = the ingested channel value
+            static_for<G::NEXT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                app_row[(size_t)(G::NC + i) * ZC] = byte_to_f32<i & 3>(st.xq[i >> 2]) * a.inv_scale;
+            });
+        }
+    }
+    __syncthreads();
+
+    auto write_out = [&](int it) {
+        uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * ZC) + z;
+        static_for<G::NC>([&](auto cc) {
+            constexpr int col = decltype(cc)::value;
+            const float v = *reinterpret_cast<const float*>(lds + R[0] + col * G::CS);
+            if constexpr (col < G::KB) hard[(size_t)col * ZC] = v < 0.0f ? 1 : 0;
+            if (app_row) app_row[(size_t)col * ZC] = v * a.inv_scale;
+        });
+        if (a.iters && z == 0) a.iters[cw] = it;
+    };
+
+    uint32_t esign_lo = 0, esign_hi = 0;
+    bool done = !present; // per lane = per codeword
+    for (int it = 1; it <= a.max_iter; ++it) {
+        esign_lo = 0; esign_hi = 0;
+        float* app_ext = done ? nullptr : app_row; // a converged codeword keeps iterating, but its soft output is final
+        static_for<G::ROWS>([&](auto lc) {
+            constexpr int L = decltype(lc)::value;
+            if constexpr (LG::group_start(L) == L) { // L leads a barrier group
+                constexpr int GE = LG::group_last(L);
+                const int nl = launder(a.n_layers);
+                if (L < nl) {
+                    if (GE < nl) {
+                        group_z64<BG, ZC, L, GE, false, false>(st, lds, R, RA, RB, rw, a, esign_lo, esign_hi, app_ext);
+                    } else { // the layer count cuts this group: its active layers one by one
+                        static_for<GE - L>([&](auto ic) {
+                            constexpr int LL = L + decltype(ic)::value;
+                            if (LL < nl) group_z64<BG, ZC, LL, LL, false, false>(st, lds, R, RA, RB, rw, a, esign_lo, esign_hi, app_ext);
+                        });
+                    }
+                    __syncthreads();
+                }
+            }
+        });
+        if (a.early_term) {
+            if (tid <= G::NCW) flags[tid] = 0;
+            __syncthreads();
+            uint32_t bad = 0;
+            bool stop = false; // wave-uniform
+            static_for<G::ROWS>([&](auto lc) {
+                constexpr int L = decltype(lc)::value;
+                if (!stop && L < launder(a.n_layers)) {
+                    bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                    if constexpr (L < 4 || (L % 4) == 3) {
+                        if (bad && !done) flags[c] = 1;
+                        stop = __all((int)(bad | (uint32_t)done | (uint32_t)__atomic_load_n(&flags[c], __ATOMIC_RELAXED))) != 0;
+                    }
+                }
+            });
+            if (bad && !done) { flags[c] = 1; flags[G::NCW] = 1; }
+            __syncthreads();
+            if (!done && flags[c] == 0) {
+                done = true;
+                write_out(it);
+            }
+            if (__builtin_amdgcn_readfirstlane(flags[G::NCW]) == 0) break;
+        }
+    }
+    if (!done) write_out(a.max_iter);
+}
+
+template <int BG, int ZC> static hipError_t launch_z64pg(const DecArgs& a, hipStream_t s) {
+    using G = Z64P<BG, ZC>;
+    auto k = nrldpc_decode_z64pg_kernel<BG, ZC>;
+    constexpr size_t lds = G::lds_bytes();
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(k, dim3((a.batch + G::NCW - 1) / G::NCW), dim3(G::RW * 64), lds, s, a);
+    return hipGetLastError();
+}
+
 // hard output only, every row active or the layer count of the build (the caller checks: anything else is the run-time-Z kernel's)
 template <int BG, int ZC> constexpr bool z64p_not_et() {
 #define NRLDPC_Z64P_CASE(b, z) if (BG == b && ZC == z) return true;

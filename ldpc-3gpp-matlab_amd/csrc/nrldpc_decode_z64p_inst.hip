@@ -25,5 +25,10 @@ hipError_t NRLDPC_CAT4(launch_decode_z64p_, NRLDPC_Z64_BG, NRLDPC_Z64_Z, NRLDPC_
 hipError_t NRLDPC_CAT(launch_decode_z64p_, NRLDPC_Z64_BG, NRLDPC_Z64_Z)(const DecArgs& a, hipStream_t stream) {
     return launch_z64p<NRLDPC_Z64_BG, NRLDPC_Z64_Z>(a, stream);
 }
+// any layer count, soft output: the general kernel of this geometry -- BG2 only (z64pg_serves; no BG1 kernel is instantiated)
+hipError_t NRLDPC_CAT(launch_decode_z64pg_, NRLDPC_Z64_BG, NRLDPC_Z64_Z)(const DecArgs& a, hipStream_t stream) {
+    if constexpr (z64pg_serves<NRLDPC_Z64_BG>()) return launch_z64pg<NRLDPC_Z64_BG, NRLDPC_Z64_Z>(a, stream);
+    else return hipErrorInvalidValue; // not reached: launch_decode asks first
+}
 #endif
 } // namespace nrldpc

@@ -56,7 +56,8 @@ NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
 // ... of which these serve fixed iteration counts only: with the parity-check stop the block-geometry split build of the
 // same size is faster (BG2 Z = 52: 0.44 against 0.54 ms; at 25 fixed iterations the packed build wins by 9 %)
 #define NRLDPC_Z64P_NOT_ET(X) X(2, 52)
-#define NRLDPC_Z64P_DECL(bg, z) hipError_t launch_decode_z64p_##bg##_##z(const DecArgs& a, hipStream_t stream);
+#define NRLDPC_Z64P_DECL(bg, z) hipError_t launch_decode_z64p_##bg##_##z(const DecArgs& a, hipStream_t stream); \
+    hipError_t launch_decode_z64pg_##bg##_##z(const DecArgs& a, hipStream_t stream);
 NRLDPC_Z64P_LIST(NRLDPC_Z64P_DECL)
 #undef NRLDPC_Z64P_DECL
 bool has_z64p_kernel(int bg, int Z, bool early_term);

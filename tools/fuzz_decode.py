@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Extended differential fuzz of the decoder kernels against the CPU oracle (the test-suite version runs 60
 cases; this runs N, default 600, biased towards the compile-time-Z sizes).  python tools/fuzz_decode.py [N] [seed]
-SMALL=1: biased towards the packed-geometry sizes (Z <= 80), every row active, hard output, ragged batches of up to 70 codewords."""
+SMALL=1: biased towards the packed-geometry sizes (Z <= 80): pipelined builds (every row active, hard output) and the general
+kernel (pruned rows, soft output), ragged batches of up to 70 codewords."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,8 @@ for i in range(N):
     if SMALL and rng.random() < 0.85:
         bg = int(rng.integers(1, 3)); Z = int(rng.choice(SMALL))
         T.run_case(pkg, orc, rng, bg, Z, int(rng.integers(1, 1 + max(8, min(70, 600 // Z)))), float(rng.uniform(-3.0, 5.0)), int(rng.integers(1, 13)),
-                   nl=0, et=bool(rng.integers(0, 2)), dt=[np.float16, np.float32][int(rng.integers(0, 2))], app=False)
+                   nl=0 if rng.random() < 0.5 else int(rng.integers(4, BG_DIMS[bg][0] + 1)), et=bool(rng.integers(0, 2)),
+                   dt=[np.float16, np.float32][int(rng.integers(0, 2))], app=bool(rng.random() < 0.3))
         if i % 50 == 49:
             print(i + 1, "cases ok", flush=True)
         continue
