@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Where do a kernel's hard decisions leave the oracle's?  CASES="bg,Z,batch,iterations ..." (fixed iteration counts, hard
+output, SNR 0.5 dB: far from convergence after one iteration, so a single stale LDS word shows); prints the mismatching
+codewords, columns and rows.  NRLDPC_LIB / NRLDPC_FORCE_GENERIC / NRLDPC_NO_PACKED select the kernel under test.
+Found the exec-mask literal defect of the packed kernels."""
 import importlib, os, sys
 import numpy as np
 ROOT="/root/repo"
