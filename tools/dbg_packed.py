@@ -5,7 +5,7 @@ codewords, columns and rows.  NRLDPC_LIB / NRLDPC_FORCE_GENERIC / NRLDPC_NO_PACK
 Found the exec-mask literal defect of the packed kernels."""
 import importlib, os, sys
 import numpy as np
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from conftest import BG_DIMS, awgn_llr
 import oracle as orc
