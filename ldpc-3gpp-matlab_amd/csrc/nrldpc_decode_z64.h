@@ -41,8 +41,8 @@
 // lane >= T of the executing wave, T a compile-time constant in 1..63: a constant exec mask applied by scalar instructions
 // (s_and_saveexec_b64), no VALU work.  The two halves of the mask are made opaque 32-bit scalars on purpose: as a 64-bit
 // constant the compiler of this ROCm release materialises it with s_mov_b64 and a 32-bit literal both for values that need
-// zero extension (0x00000000ffffffff) and for values that need sign extension (0xfffffffffffffc00); the hardware zero-extends
-// (tools/ubench/smov64_literal.hip), and the packed kernels decoded wrongly until the halves were separated (tools/dbg_packed.py found it: bit errors
+// zero extension (0x00000000ffffffff) and for values that need sign extension (0xfffffffffffffc00); the hardware does one of
+// the two, and the packed kernels decoded wrongly until the halves were separated (tools/dbg_packed.py found it: bit errors
 // after ONE iteration that later iterations mostly repaired -- tests/test_decode_gpu.py::test_packed_kernels_iteration_by_iteration).
 #ifdef NRLDPC_EXP_LANE_CMP
 #define NRLDPC_LANE_GE(T) ((int)(threadIdx.x & 63) >= (T))
