@@ -1054,7 +1054,8 @@ template <int BG, int ZC, int NL> constexpr bool z64_split_default() {
 #endif
     // pruned layer counts: BG1 Z = 384 {5, 13, 24} -- with the parity-check stop +10 % / +21 % / +14 %, fixed-25 -3 % /
     // +6 % / +4 % (profiles/r03_forms_nl.txt); the BG2 counts of BASELINE configs[2] lose 10-19 % and stay with the row form
-    if (NL != BGT<BG>::ROWS) return BG == 1 && ZC == 384;
+    // BG2 Z = 208 with 21 rows (the reference's default operating point): split 1.42 / 0.94 ms, row form 1.49 / 1.04, general kernel 1.71 / 1.27
+    if (NL != BGT<BG>::ROWS) return (BG == 1 && ZC == 384) || (BG == 2 && ZC == 208);
     if (BG == 1)
         return ZC == 60 || ZC == 64 || ZC == 104 || ZC == 112 || ZC == 120 || ZC == 128 || ZC == 176 || ZC == 208 || ZC == 224 ||
                ZC == 240 || ZC == 256 || ZC == 288 || ZC == 384;

@@ -69,9 +69,10 @@ NRLDPC_Z64P_NL_LIST(NRLDPC_Z64P_NL_DECL)
 #undef NRLDPC_Z64P_NL_DECL
 // pruned layer counts with software-pipelined builds of their own (one translation unit each): the active-layer counts
 // of BASELINE.json's rate-matching sweep at BG2 Z=384 (R = 1/4 ... 2/3 -> 32, 22, 17, 12, 9, 7 rows; R = 1/5 is all 42),
-// of its BG1 Z=384 R=8/9 shard (5 rows) and of BG1 R = 2/3 and 1/2 (13, 24).  Every other count runs the general kernel.
+// of its BG1 Z=384 R=8/9 shard (5 rows) and of BG1 R = 2/3 and 1/2 (13, 24); BG2 Z=208 with 21 rows is the operating point of the
+// reference's plot_BLER_vs_SNR.m defaults (A = 3842, R = 1/3: two code blocks).  Every other count runs the general kernel.
 #define NRLDPC_Z64_NL_LIST(X) \
-    X(1, 384, 5) X(1, 384, 13) X(1, 384, 24) X(2, 384, 32) X(2, 384, 22) X(2, 384, 17) X(2, 384, 12) X(2, 384, 9) X(2, 384, 7)
+    X(1, 384, 5) X(1, 384, 13) X(1, 384, 24) X(2, 384, 32) X(2, 384, 22) X(2, 384, 17) X(2, 384, 12) X(2, 384, 9) X(2, 384, 7) X(2, 208, 21)
 #define NRLDPC_Z64_NL_DECL(bg, z, nl) hipError_t launch_decode_z64_##bg##_##z##_nl##nl(const DecArgs& a, hipStream_t stream);
 NRLDPC_Z64_NL_LIST(NRLDPC_Z64_NL_DECL)
 #undef NRLDPC_Z64_NL_DECL

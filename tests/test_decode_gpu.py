@@ -65,7 +65,11 @@ def test_hard_output_kernels_iteration_by_iteration(pkg, orc, bg):
             run_case(pkg, orc, rng, bg, Z, B, -2.0 if bg == 1 else -3.0, iters, et=False, app=False,
                      dt=np.float16 if (Z + iters) % 2 else np.float32)
         run_case(pkg, orc, rng, bg, Z, B, 0.3 if bg == 1 else -0.5, 12, et=True, app=False)
-    if bg == 2:  # NRLDPC_Z64P_NL_LIST: a pruned layer count with packed builds of its own (BASELINE configs[0]: Z = 20, 12 rows)
+    if bg == 2:  # pruned layer counts with pipelined builds of their own: the reference's default point (Z = 208, 21 rows) ...
+        for iters in (1, 2, 3):
+            run_case(pkg, orc, rng, 2, 208, 5, -1.0, iters, nl=21, et=False, app=False)
+        run_case(pkg, orc, rng, 2, 208, 5, 1.0, 12, nl=21, et=True, app=False)
+    if bg == 2:  # ... and NRLDPC_Z64P_NL_LIST (BASELINE configs[0]: Z = 20, 12 rows), packed geometry
         for iters in (1, 2, 3):
             run_case(pkg, orc, rng, 2, 20, 37, 1.0, iters, nl=12, et=False, app=False)
         run_case(pkg, orc, rng, 2, 20, 37, 3.0, 12, nl=12, et=True, app=False)
