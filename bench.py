@@ -138,6 +138,97 @@ def synth_llr(torch, codec, batch, seed, dev):
     return info, llr.to(torch.float16).contiguous()
 
 
+CFG5_TOTAL, CFG5_LAYERS, CFG5_E, CFG5_ESN0 = 65536, 5, 9478, 7.5  # BASELINE.json configs[4]: BG1 Z=384 R=8/9, early termination
+
+
+def cfg5_strong_leg(torch, nrldpc, dist, args, world, rank, local_rank, dev, valu_insts_per_edge_iter):
+    """BASELINE.json configs[4] next to the headline when the job has more than one rank (or --cfg5): 65536 BG1 Z=384 R=8/9
+    codewords (5 active rows, 27 of the 68 columns transmitted), early termination, STRONG-scaled -- the total is fixed and
+    rank r decodes the contiguous slice [r*total/N, (r+1)*total/N) on its own GPU with its own handle, no data-path
+    collective.  Timed like the headline: barrier + synchronize on both sides, max over ranks; every rank's
+    kernel time (event pairs on the launch stream) is gathered so that the line carries a per-GPU figure.  Returns the
+    leg's record on rank 0, None elsewhere."""
+    total = args.cfg5_total
+    lo, hi = total * rank // world, total * (rank + 1) // world
+    n = hi - lo
+    codec = nrldpc.Codec(BG, Z, max_iter=ITERS, n_layers=CFG5_LAYERS, early_term=True, llr_dtype=np.float16, device_id=local_rank)
+    g = torch.Generator(device=dev)
+    llr = torch.empty((n, N_CW), device=dev, dtype=torch.float16)
+    info = torch.empty((n, K), device=dev, dtype=torch.uint8)
+    mu = 2.0 * 10.0 ** (CFG5_ESN0 / 10.0)
+    for c0 in range(0, n, 4096):  # chunked: the fp32 noise of a whole shard would be several GB
+        c1 = min(n, c0 + 4096)
+        g.manual_seed(0xC0DE + 5 + (lo + c0))  # a function of the GLOBAL codeword index: the same job for every N
+        info[c0:c1] = torch.randint(0, 2, (c1 - c0, K), generator=g, device=dev, dtype=torch.uint8)
+        cw = torch.empty((c1 - c0, N_CW), device=dev, dtype=torch.uint8)
+        codec.encode_dev(info[c0:c1].data_ptr(), c1 - c0, cw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        x = (1.0 - 2.0 * cw.to(torch.float32)) * mu + (2.0 * mu) ** 0.5 * torch.randn((c1 - c0, N_CW), generator=g, device=dev)
+        x[:, : 2 * Z] = 0.0
+        x[:, 2 * Z + CFG5_E:] = 0.0
+        llr[c0:c1] = x.to(torch.float16)
+    hard = torch.empty((n, K), device=dev, dtype=torch.uint8)
+    its = torch.empty(n, device=dev, dtype=torch.int32)
+    tstream = torch.cuda.current_stream()
+
+    def step():
+        if n:
+            codec.decode_dev(llr.data_ptr(), n, hard.data_ptr(), its.data_ptr(), None, tstream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    steps = max(1, args.cfg5_steps)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for _ in range(2):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record(tstream)
+        step()
+        e1.record(tstream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    mean_it = float(its.float().mean().item()) if n else 0.0
+    bler = float((hard != info).any(dim=1).float().mean().item()) if n else 0.0
+    mine = [elapsed, kms, mean_it, bler, float(n)]
+    if dist is not None:
+        t = torch.tensor(mine, device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)  # five numbers per rank: the leg's bookkeeping, not its data path
+        rows = [[float(v) for v in r.tolist()] for r in allr]
+    else:
+        rows = [mine]
+    codec.close()
+    if rank != 0:
+        return None
+    elapsed = max(r[0] for r in rows)
+    edges5 = 79  # base-graph edges of BG1's rows 0..4
+    cols_in = KB + 4 + (CFG5_LAYERS - 4)  # columns the 5 active rows reach
+    per_gpu = []
+    for r in rows:
+        ni, ms = int(r[4]), r[1]
+        io_bytes = ni * (cols_in * Z * 2 + K)  # fp16 LLRs of the columns read + one byte per hard bit
+        rec = {"codewords": ni, "kernel_ms": ms, "mean_iterations": r[2], "bler": r[3],
+               "value": ni * K / ms / 1e6 if ms > 0 else None, "unit": "Gbit/s",
+               "hbm_frac": (io_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else None}
+        if valu_insts_per_edge_iter and ms > 0:
+            insts = ni * r[2] * edges5 * (Z / 64.0) * valu_insts_per_edge_iter
+            rec["valu_issue_frac_estimate"] = insts / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS
+        per_gpu.append(rec)
+    return {"workload": "BASELINE configs[4]: BG1 Z=384 R=8/9 (5 active rows, E=%d), <=%d iterations with the parity-check stop, "
+                        "%d codewords in the job, QPSK/AWGN Es/N0=%.1f dB" % (CFG5_E, ITERS, total, CFG5_ESN0),
+            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+            "value": total * steps * K / elapsed / 1e9, "unit": "Gbit/s", "per_gpu": per_gpu,
+            "note": "contiguous slices of the job per rank, no data-path collective; value = whole job / max-over-ranks wall time; "
+                    "per_gpu.hbm_frac = compulsory input + output bytes / kernel time / 8 TB/s; valu_issue_frac_estimate prices "
+                    "the EXECUTED iterations at the headline kernel's measured VALU instructions per edge and iteration (the parity "
+                    "pass and the prologue are not in it: an under-estimate)"}
+
+
 def cpu_baseline(llr_host_f64, info_host, rule):
     """Reference-semantics CPU path (flooding sum-product, double, parity-check early stop, the
     comm.LDPCDecoder configuration of NRLDPCDecoder.m:120) restated in oracle/.  `value` is the single-thread
@@ -224,10 +315,24 @@ def dry_run(args, torch):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the collectives of the per-GPU bookkeeping and of the cfg5_strong leg: all_gather of a few numbers per rank
+    leg = None
+    if dist is not None:
+        lo, hi = args.cfg5_total * rank // world, args.cfg5_total * (rank + 1) // world
+        barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.001 * (rank + 1))
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0, float(hi - lo)], dtype=torch.float64)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        leg = {"dry_run": True, "scaling": "strong", "n_gpus": world,
+               "per_gpu": [{"codewords": int(r[1].item()), "seconds": float(r[0].item())} for r in allr]}
     if rank == 0:
         print(json.dumps({"metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
                           "dry_run": True, "value": None, "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak"}), flush=True)
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak",
+                          "cfg5_strong": leg}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -242,6 +347,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024, help="codewords for the all-core CPU baselines (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-path leg")
     ap.add_argument("--no-early-term", action="store_true", help="skip the extra early_term leg (reference semantics)")
+    ap.add_argument("--cfg5", action="store_true", help="also run the cfg5_strong leg at N = 1 (it always runs with more than one rank)")
+    ap.add_argument("--cfg5-total", type=int, default=CFG5_TOTAL, help="codewords in the WHOLE job of the cfg5_strong leg")
+    ap.add_argument("--cfg5-steps", type=int, default=5, help="timed passes of the cfg5_strong leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-time (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="test aid for 1-GPU boxes: every rank uses device 0 (use "
                     "with --backend gloo; RCCL refuses two ranks on one GPU)")
@@ -313,6 +421,13 @@ def main():
         elapsed = float(t.item())
 
     bler = float((hard != info).any(dim=1).float().mean().item())
+    # every rank's kernel time, for the per-GPU roofline fractions of the line (bookkeeping: one number per rank)
+    kms_all = [kernel_ms]
+    if dist is not None:
+        t = torch.tensor([kernel_ms], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        kms_all = [float(x.item()) for x in allr]
 
     # Extra leg, outside the timed region: the reference's own mode -- 'Parity check satisfied' (NRLDPCDecoder.m:120) --
     # on the same LLRs (rank 0 only; never `value`, whose workload is the fixed-25 configuration BASELINE.json names)
@@ -332,11 +447,18 @@ def main():
                  "max_iterations": ITERS, "EsN0_dB": ESN0_DB, "bler": float((hard_et != info).any(dim=1).float().mean().item()),
                  "note": "parity-check stop per codeword (the reference's only mode), same LLRs, median of 5 launches after 2"}
 
+    kid = nrldpc.load().nrldpc_kernel_id().decode()
+    bid = nrldpc.load().nrldpc_build_id().decode()
+    tag, pmc, tr, mix = _profile(kid)
+    insts_headline = (pmc.get("SQ_INSTS_VALU", {}).get("mean_per_launch") or 0.0) * (batch / float(BATCH))
+    insts_per_edge_iter = insts_headline / (batch * ITERS * NNZ * Z / 64.0) if insts_headline else None
+    # BASELINE configs[4], strong-scaled over the ranks of the job (every rank takes part: it has a barrier of its own)
+    cfg5 = None
+    if world > 1 or args.cfg5:
+        cfg5 = cfg5_strong_leg(torch, nrldpc, dist, args, world, rank, local_rank, dev, insts_per_edge_iter)
+
     if rank == 0:
         value = world * batch * args.steps * K / elapsed / 1e9
-        kid = nrldpc.load().nrldpc_kernel_id().decode()
-        bid = nrldpc.load().nrldpc_build_id().decode()
-        tag, pmc, tr, mix = _profile(kid)
         traffic = tr.get("hbm_bytes_per_launch")
         scale = batch / float(BATCH)  # the committed profile is of the default batch
         if traffic is not None:
@@ -361,8 +483,6 @@ def main():
                 "wave_cycle_split": None if not wc else {
                     "issuing": c("SQ_ACTIVE_INST_ANY") / wc, "issue_stalled": c("SQ_WAIT_INST_ANY") / wc,
                     "parked_at_waitcnt_or_barrier": c("SQ_WAIT_ANY") / wc},
-                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves: x4 / (1024 SIMDs x busy cycles) prices every op at 4 cycles
-                "valu_pipe_busy_at_4_cycles_per_op": (4.0 * c("SQ_ACTIVE_INST_VALU") / (1024 * cyc)) if (c("SQ_ACTIVE_INST_VALU") and cyc) else None,
                 "lds": None if not (c("SQ_LDS_IDX_ACTIVE") and cyc) else {
                     "busy_frac": c("SQ_LDS_IDX_ACTIVE") / (256 * cyc), "bank_conflict_cycles": c("SQ_LDS_BANK_CONFLICT"),
                     "note": "SQ_LDS_IDX_ACTIVE / (256 CUs x busy cycles): the LDS array is not the bound either"},
@@ -371,13 +491,17 @@ def main():
                         "on gfx950 (profiles/r03_ubench_valu_rates.txt), which cycle_weighted accounts for"})
         if mix and mix.get("valu_ns_per_iteration_all_waves_of_a_row"):
             # static: disassembly of the loaded kernels x measured per-opcode issue intervals (tools/isa_mix.py): the time the
-            # launch needs if the VALU pipes never idle.  Per CU and iteration every row of 2 resident codewords is processed once:
-            # ns(per row-wave set) x (Z/64 waves x 2 codewords / 4 SIMDs)
-            per_simd = mix["valu_ns_per_iteration_all_waves_of_a_row"] * (Z / 64.0) * 2.0 / 4.0
-            valu_ms = per_simd * ITERS * (batch / 2.0 / 256.0) * 1e-6
+            # launch needs if the VALU pipes never idle = VALU-ns of one iteration of one codeword (ns per row-wave set x Z/64
+            # waves), x iterations x codewords, spread over the chip's 1024 SIMDs -- independent of how many codewords a CU holds
+            valu_ms = mix["valu_ns_per_iteration_all_waves_of_a_row"] * (Z / 64.0) * ITERS * batch / 1024.0 * 1e-6
             roof["cycle_weighted"] = {"valu_bound_ms_per_launch": valu_ms, "frac": valu_ms / kernel_ms,
                                       "valu_ns_per_iteration_all_waves_of_a_row": mix["valu_ns_per_iteration_all_waves_of_a_row"],
                                       "source": "profiles/%s_headline_isa_mix.json" % tag}
+        if roof.get("insts_per_launch"):  # every rank decodes the same number of codewords for the same 25 iterations
+            roof["per_gpu"] = [{"rank": r, "kernel_ms": ms, "frac": roof["insts_per_launch"] / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS}
+                               for r, ms in enumerate(kms_all)]
+        else:
+            roof["per_gpu"] = [{"rank": r, "kernel_ms": ms, "frac": None} for r, ms in enumerate(kms_all)]
         roof["profile"] = {"tag": tag, "nrldpc_kernel_id": kid, "nrldpc_build_id": bid,
                            "matches_loaded_library": tag is not None,
                            "source": None if tag is None else "profiles/%s_bench_pmc_summary.json, profiles/%s_bench_kernel_stats.csv "
@@ -410,6 +534,7 @@ def main():
             "bler": bler,
             "bler_match": bler_match(),
             "early_term": early,
+            "cfg5_strong": cfg5,
         }
         if world == 1:  # CPU baseline and host-path legs at N = 1 only
             # the host-path leg first: the all-core CPU baselines spend the process's CPU quota (the MI355X boxes grant 16

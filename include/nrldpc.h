@@ -128,7 +128,10 @@ int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uin
 /* The same for data that is already ON the devices: shard i (entry i of device_ids) decodes batch[i] codewords from
  * d_llr[i] into d_hard[i] (and d_iters[i] when d_iters and d_iters[i] are non-null); every pointer of shard i is
  * device memory of device_ids[i], in cfg.llr_dtype (F32 / F16).  One host thread per shard launches on the shard's
- * own stream; the call returns when every shard's stream is idle.  No host copy, no collective: this is the form that
+ * own stream; the call returns when every shard's stream is idle.  Ordering: the shard streams are private, so each shard
+ * first waits (hipDeviceSynchronize on its device) for everything the caller has ALREADY submitted to that device -- LLRs a
+ * kernel of the caller's is still writing when the call is made are complete before the decoder reads them; work submitted
+ * from another thread DURING the call is not ordered against it.  No host copy, no collective: this is the form that
  * scales with the number of GPUs (the host-pointer form above is bounded by the host's copy bandwidth). */
 int nrldpc_pool_decode_dev(nrldpc_pool_handle p, const void* const* d_llr, const int32_t* batch, uint8_t* const* d_hard,
                            int32_t* const* d_iters);

@@ -107,6 +107,13 @@ def load():
             if _build._stale():
                 path = _build.build_lib()
     L = C.CDLL(path)
+    # the ABI revision first, before any symbol that only this revision exports is touched: a stale library (NRLDPC_LIB skips
+    # the build-id check) must fail with this message, not with a ctypes AttributeError on a missing symbol
+    abi = getattr(L, "nrldpc_abi_version", None)
+    have = abi() if abi is not None else 0
+    if have != ABI_VERSION:
+        raise RuntimeError("libnrldpc_hip.so speaks ABI revision %s, this binding %d"
+                           % (have if abi is not None else "< 3 (no nrldpc_abi_version)", ABI_VERSION))
     L.nrldpc_build_id.restype = C.c_char_p
     L.nrldpc_kernel_id.restype = C.c_char_p
     if not os.environ.get("NRLDPC_LIB") and L.nrldpc_build_id().decode() != _build.source_id():
@@ -134,8 +141,6 @@ def load():
     L.nrldpc_pool_last_split.argtypes = [vp, C.POINTER(i32)]
     L.nrldpc_pool_decode_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp)]
     L.nrldpc_pool_size.argtypes = [vp]
-    if L.nrldpc_abi_version() != ABI_VERSION:
-        raise RuntimeError("libnrldpc_hip.so speaks ABI revision %d, this binding %d" % (L.nrldpc_abi_version(), ABI_VERSION))
     L.nrldpc_pool_destroy.argtypes = [vp]
     L.nrldpc_pool_destroy.restype = None
     L.nrldpc_set_timing.argtypes = [vp, i32]
@@ -278,7 +283,9 @@ class CodecPool:
 
     def decode_dev(self, d_llr, batch, d_hard, d_iters=None):
         """nrldpc_pool_decode_dev: shard i decodes batch[i] codewords at device address d_llr[i] (memory of
-        device_ids[i]) into d_hard[i]; returns when every shard's stream is idle.  No host copies."""
+        device_ids[i]) into d_hard[i]; returns when every shard's stream is idle.  No host copies.  Work already queued on a
+        shard's device when the call is made (e.g. the torch kernel still producing d_llr[i]) completes before the decoder
+        starts: each shard synchronizes its device first (nrldpc.h)."""
         n = len(self.device_ids)
         if not (len(d_llr) == len(batch) == len(d_hard) == n):
             raise NRLDPCError("one entry per shard expected")

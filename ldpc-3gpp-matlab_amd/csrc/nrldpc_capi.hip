@@ -918,6 +918,10 @@ struct nrldpc_pool {
         nrldpc_handle h = hs[i];
         DEVICE_SCOPE(h);
         if (!streams[i]) HIP_TRY(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));
+        // The shard's stream is private and non-blocking, so it is ordered against nothing the caller queued: wait for
+        // everything already submitted to this device (whatever stream produced d_llr[i]) before the launch.  The call is
+        // synchronous anyway -- it returns when every shard is done -- so this costs no overlap the caller could have had.
+        HIP_TRY(hipDeviceSynchronize());
         const int r = nrldpc_decode_dev(h, dv_llr[i], dv_batch[i], dv_hard[i], dv_iters ? dv_iters[i] : nullptr, nullptr, streams[i]);
         if (r != NRLDPC_OK) return r;
         HIP_TRY(hipStreamSynchronize(streams[i]));
@@ -965,6 +969,9 @@ int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t
     NRLDPC_API_BEGIN
     if (!cfg || !device_ids || !out) return fail(NRLDPC_ERR_ARG, "null cfg/device_ids/out");
     *out = nullptr;
+    // before anything reads *cfg as this library's struct: a caller built against another revision may have passed a smaller one
+    if (cfg->struct_size != (uint32_t)sizeof(nrldpc_cfg))
+        return fail(NRLDPC_ERR_ARG, "nrldpc_cfg.struct_size does not match this library (set it to sizeof(nrldpc_cfg); ABI revision mismatch?)");
     if (n_devices < 1 || n_devices > 64) return fail(NRLDPC_ERR_ARG, "n_devices must be in 1..64");
     if (chunks_per_device < 1 || chunks_per_device > 64) return fail(NRLDPC_ERR_ARG, "chunks_per_device must be in 1..64");
     nrldpc_pool* p = new nrldpc_pool();

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void nrldpc_crc_attach_lane_kernel(const CrcAt
 static int waves_for(int C) { return C < 4 ? C : 4; }
 
 hipError_t launch_crc_attach(const CrcAttachArgs& a, hipStream_t stream) {
-    if (a.C == 1 && a.Kp <= CRC_LANE_MAX_BITS && a.n_tb >= 4096) { // short blocks, enough of them to fill the chip lane-wise
+    // (the lane kernels are written for the one-code-block layout of TS 38.212: no code-block CRC, B = K')
+    if (a.C == 1 && a.Lcb == 0 && a.B == a.Kp && a.Kp <= CRC_LANE_MAX_BITS && a.n_tb >= 4096) { // short blocks, enough of them to fill the chip lane-wise
         hipLaunchKernelGGL(nrldpc_crc_attach_lane_kernel, dim3((a.n_tb + 255) / 256), dim3(256), 0, stream, a);
         return hipGetLastError();
     }
@@ -268,7 +269,7 @@ hipError_t launch_crc_attach(const CrcAttachArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_crc_check(const CrcArgs& a, hipStream_t stream) {
-    if (a.C == 1 && a.Kp <= CRC_LANE_MAX_BITS && a.n_tb >= 4096) {
+    if (a.C == 1 && a.Lcb == 0 && a.B == a.Kp && a.Kp <= CRC_LANE_MAX_BITS && a.n_tb >= 4096) {
         hipLaunchKernelGGL(nrldpc_crc_check_lane_kernel, dim3((a.n_tb + 255) / 256), dim3(256), 0, stream, a);
         return hipGetLastError();
     }

@@ -347,7 +347,10 @@ hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes
         NRLDPC_Z64P_NL_LIST(NRLDPC_Z64P_NL_CASE)
 #undef NRLDPC_Z64P_NL_CASE
     }
-    if (!a.app && a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) && has_z64p_kernel(bg, a.Z, a.early_term != 0)) { // the packed builds: all rows, hard output
+    // the packed builds: hard output; every row active, or any other layer count as a run-time prefix (NL_RT; NRLDPC_NO_RT=1
+    // sends those to the kernels that served them before -- A/B)
+    static const bool no_rt = getenv("NRLDPC_NO_RT") != nullptr;
+    if (!a.app && (a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) || !no_rt) && has_z64p_kernel(bg, a.Z, a.early_term != 0)) {
 #define NRLDPC_Z64P_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64p_##b##_##z(a, stream);
         NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE

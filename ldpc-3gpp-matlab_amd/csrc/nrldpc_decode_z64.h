@@ -98,6 +98,11 @@ constexpr int z64p_rw(int BG, int Z) {
     return NRLDPC_Z64P_RW;
 #endif
     (void)BG;
+    // Large lifting sizes that do not split into full waves in the block geometry (9, 11, 5 or 3 times a power of two: blocks of
+    // 40-48 rows leave 25-37 % of the lanes idle): 6-wave halves -- the 12-wave workgroup shape of Z = 384's split kernel -- carry
+    // 352 rows (4 x 88, 2 x 176, 1 x 352) or 384 (4 x 96), 5-wave halves 288 (2 x 144, 1 x 288) or 320 (2 x 160, 1 x 320)
+    if (Z == 88 || Z == 96 || Z == 176 || Z == 352) return 6;
+    if (Z == 144 || Z == 160 || Z == 288 || Z == 320) return 5;
     int best = 1, fill = -1;
     for (int rw = 1; rw <= 4; rw *= 2) {
         const int f = (64 * rw / Z) * Z * 1000 / (64 * rw);
@@ -142,7 +147,7 @@ template <int BG, int ZC, int NL> constexpr int z64_ncwg_nl() {
 #ifdef NRLDPC_Z64_NCWG
     return NRLDPC_Z64_NCWG;
 #endif
-    return (BG == 1 && z64_nwv(ZC) == 6 && NL <= 6) ? 1 : z64_ncwg<BG, ZC>();
+    return (BG == 1 && z64_nwv(ZC) == 6 && NL != NL_RT && NL <= 6) ? 1 : z64_ncwg<BG, ZC>();
 }
 
 // Extension LLRs as floats in VGPRs (DecState::xf) for the fixed-iteration builds with register room: BG1 shapes sized
@@ -164,7 +169,7 @@ template <int BG, int ZC, int NCWG, int NL = BGT<BG>::ROWS> constexpr int z64_wp
 #ifdef NRLDPC_Z64_WPE
     return NRLDPC_Z64_WPE;
 #endif
-    if (BG == 1 && z64_nwv(ZC) == 6 && NL <= 6) return 6;
+    if (BG == 1 && z64_nwv(ZC) == 6 && NL != NL_RT && NL <= 6) return 6;
     return BG == 2 ? 6 : (z64_nwv(ZC) == 8 || z64_nwv(ZC) == 5 || z64_nwv(ZC) == 4 || z64_nwv(ZC) == 3) ? 4 : 3;
 }
 
@@ -172,7 +177,9 @@ template <int BG, int ZC, int NCWG, int NL = BGT<BG>::ROWS> constexpr int z64_wp
 // pipelined kernels are instantiated for); only the mirror-coherence analysis depends on it.
 template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROWS> struct Z64 : BGD<BG> {
     static constexpr int NL = NL_;
-    static constexpr int NNZA = BGD<BG>::row_ptr(NL_); // edges of the active rows
+    static constexpr bool RT = NL_ == NL_RT;           // the layer count is a run-time prefix of the all-rows tables (nrldpc_device.h)
+    static constexpr int NLT = nl_rows<BG>(NL_);       // rows the tables cover
+    static constexpr int NNZA = BGD<BG>::row_ptr(NLT); // edges of the active rows
     static constexpr bool PACKED = z64_packed(ZC);
     static constexpr int BLK = z64_blk(ZC);             // rows (ring words) per wave
     static_assert(BLK >= (PACKED ? 2 : 4) && ZC % BLK == 0, "no usable block size for this lifting size");
@@ -185,6 +192,23 @@ template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROW
     // a shift P as (index of the thread's base address, byte offset from it)
     static constexpr int ridx(int P) { return P / BLK; }
     static constexpr int roff(int P) { return 4 * (P % BLK) * PW; }
+    // Where edge (column c, shift P) of this thread's row lives: base register R[pb(c, P)] plus the immediate po(c, P).
+    // Block geometry: R[k] = the thread's word of ring block (w + k) mod NWV of column 0.  Packed geometry: ONE base, R[0] = 4 g
+    // -- the thread's word of the guard in front of column 0 -- so that the twin of a word (NROWP words below it / above it)
+    // is the same register with another immediate; an LDS instruction's immediate offset is 16 bits, so a workgroup image
+    // beyond 64 KB (BG1 with 5- or 6-wave halves) addresses its columns from HICOL on from a second base, R[1] = R[0] + HIOFF.
+    static constexpr int NROWP = PACKED ? ZC * PW : 0; // packed: row lanes of the workgroup = words of one copy of a ring
+    static constexpr int hicol() {
+        if (!PACKED) return BGD<BG>::NC;
+        for (int c = 0; c < BGD<BG>::NC; ++c)
+            if (GUARD + c * CS + 4 * (ZC - 1) * PW + 4 * NROWP > 65535) return c; // (the immediate of its twin above the last ring position)
+        return BGD<BG>::NC;
+    }
+    static constexpr int HICOL = hicol();
+    static constexpr int HIOFF = HICOL * CS;
+    static constexpr int NBASE = PACKED ? (HICOL < BGD<BG>::NC ? 2 : 1) : NWV;
+    static constexpr int pb(int c, int P) { return PACKED ? (c >= HICOL ? 1 : 0) : ridx(P); }
+    static constexpr int po(int c, int P) { return c * CS + roff(P) + (PACKED ? GUARD - (c >= HICOL ? HIOFF : 0) : 0); }
     static constexpr int NCWG = NCWG_;                  // codewords per workgroup
     static constexpr int ILS = z64_set_index(ZC);
     static constexpr int shift(int e) { return (BG == 1 ? nr_bg1_shift[ILS][e] : nr_bg2_shift[ILS][e < NR_BG2_NNZ ? e : 0]) % ZC; }
@@ -209,6 +233,36 @@ template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROW
     }
     static constexpr bool twin_b(int e, bool full) {
         return !full || last_on_column(e) || shift(next_on_column(e)) % BLK > shift(e) % BLK;
+    }
+    // Run-time layer count (RT).  Edge e's column is read next by the next edge n on it in a LATER row -- if that row is active --
+    // and otherwise (e is the column's last ACTIVE writer: n_layers <= row(n)) by the column's first edge in the next iteration,
+    // by the parity pass through every active edge, and by the hard decision through the primary copy: both twins then.  So a
+    // twin is owed never, always (n needs it, or e is the column's last edge in the table), or only when e is the last active
+    // writer -- a scalar comparison of n_layers with twin_last_row(e) around that one store.  With every row active this writes
+    // exactly what the all-rows build writes.
+    static constexpr int TW_NEVER = 0, TW_ALWAYS = 1, TW_IF_LAST = 2;
+    static constexpr int row_of(int e) {
+        int r = 0;
+        while (BGD<BG>::row_ptr(r + 1) <= e) ++r;
+        return r;
+    }
+    static constexpr int later_on_column(int e) {
+        const int c = BGD<BG>::col(e);
+        for (int i = e + 1; i < BGD<BG>::NNZ; ++i)
+            if (BGD<BG>::col(i) == c) return i;
+        return -1;
+    }
+    static constexpr int twin_last_row(int e) { return later_on_column(e) < 0 ? BGD<BG>::ROWS : row_of(later_on_column(e)); }
+    static constexpr int twin_mode_a(int e, bool full) {
+        if (!RT) return twin_a(e, full) ? TW_ALWAYS : TW_NEVER;
+        if (shift(e) % BLK == 0) return TW_NEVER;
+        const int n = later_on_column(e);
+        return (n < 0 || shift(n) % BLK < shift(e) % BLK) ? TW_ALWAYS : TW_IF_LAST;
+    }
+    static constexpr int twin_mode_b(int e, bool full) {
+        if (!RT) return twin_b(e, full) ? TW_ALWAYS : TW_NEVER;
+        const int n = later_on_column(e);
+        return (n < 0 || shift(n) % BLK > shift(e) % BLK) ? TW_ALWAYS : TW_IF_LAST;
     }
     // + one trailing guard (the last column's block-0 twin write overshoots into it) + termination flags
     static constexpr size_t lds_bytes() { return (size_t)NCWG * CWS + GUARD + 16 * ((NCWG + 1 + 3) / 4); }
@@ -255,13 +309,15 @@ template <int BG, int ZC, int NL> constexpr bool z64s_single() {
 #ifdef NRLDPC_Z64S_SINGLE
     return NRLDPC_Z64S_SINGLE != 0;
 #endif
+    if (NL == NL_RT) return true; // a run-time layer count may end an iteration after any layer: no merged groups to cut
     return BG == 2 || 24 / (2 * Z64<BG, ZC, 1, NL>::NWV) <= 2;
 }
 template <int BG, int ZC, int NL> constexpr int z64s_variant() {
     return (z64s_dual<BG, ZC, NL>() ? SPLIT_DUAL : 0) | (z64s_single<BG, ZC, NL>() ? SPLIT_SINGLE : 0);
 }
 // the barrier-group table of a kernel form (H < 0: one thread per check row)
-template <int BG, int ZC, int NL, int H> using LGof = LayerGroups<BG, NL, (H >= 0 && z64s_single<BG, ZC, NL>())>;
+// (a run-time layer count may end an iteration after any layer, so its builds -- both forms -- have one-layer groups)
+template <int BG, int ZC, int NL, int H> using LGof = LayerGroups<BG, NL, (NL == NL_RT || (H >= 0 && z64s_single<BG, ZC, NL>()))>;
 
 // One base-graph layer for this thread's check row, split into phases so that the layers of a
 // column-disjoint barrier group can issue all their LDS reads first and share one mirror dispatch.
@@ -284,11 +340,11 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
     float t[ncore];
     float lam, m1, M1, M2;
 
-    __device__ __forceinline__ void load(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
+    __device__ __forceinline__ void load(const char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE]) {
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int P = G::shift(e0 + j);
-            t[j] = *reinterpret_cast<const float*>(lds + R[G::ridx(P)] + G::col(e0 + j) * G::CS + G::roff(P));
+            t[j] = *reinterpret_cast<const float*>(lds + R[G::pb(G::col(e0 + j), P)] + G::po(G::col(e0 + j), P));
         });
     }
 
@@ -297,18 +353,23 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
     // and folded into the min search BEFORE the barrier that separates the two groups.
     static constexpr unsigned long long prev_written() {
         using LG = LGof<BG, ZC, NL, H>;
+        // run-time layer count: which group ends an iteration is not a compile-time fact, so all of group 0's edges are late.
+        // (Measured on BG1 Z = 384, one session, against timing-only builds that took the late set of ONE layer count as a
+        // compile-time fact: 0...1.5 % -- and a build that decided per edge at run time, behind scalar branches on a column mask,
+        // was 4-10 % SLOWER than this: the branches split the layer into basic blocks the scheduler cannot interleave.)
+        if (G::RT && LG::group_index(L) == 0) return ~0ull;
         return LG::group_mask((LG::group_index(L) + LG::ngroups() - 1) % LG::ngroups());
     }
     static constexpr bool is_late(int j) { return (prev_written() >> G::col(e0 + j)) & 1ull; }
     float pm1, pm2;  // partial two-smallest search
     uint32_t pS;     // partial sign parity
 
-    template <bool LATE> __device__ __forceinline__ void load_part(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
+    template <bool LATE> __device__ __forceinline__ void load_part(const char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE]) {
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (LayerZ64::is_late(j) == LATE && LayerZ64::owned(j)) {
                 constexpr int P = G::shift(e0 + j);
-                t[j] = *reinterpret_cast<const float*>(lds + R[G::ridx(P)] + G::col(e0 + j) * G::CS + G::roff(P));
+                t[j] = *reinterpret_cast<const float*>(lds + R[G::pb(G::col(e0 + j), P)] + G::po(G::col(e0 + j), P));
             }
         });
     }
@@ -382,7 +443,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
         pm1 = fminf(pm1, o.x);
     }
     // pass 2 for all (owned) edges after every part has been tracked
-    template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
+    template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], const DecArgs& a) {
         m1 = pm1;
         // magnitudes carrying the row's sign parity: M | (S & signbit) in one v_bitop3_b32 (0xF8 = a | (b & c))
         // a.beta holds 2^23 - beta here (set up by the pipelined kernels, see scale_mag_magic)
@@ -404,12 +465,12 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
                 f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
                 const float v = tj + r;
                 t[j] = v;
-                *reinterpret_cast<float*>(lds + R[G::ridx(P)] + G::col(e0 + j) * G::CS + G::roff(P)) = v;
+                *reinterpret_cast<float*>(lds + R[G::pb(G::col(e0 + j), P)] + G::po(G::col(e0 + j), P)) = v;
             }
         });
     }
 
-    __device__ __forceinline__ void update(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
+    __device__ __forceinline__ void update(DecState<BG>& st, char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], const DecArgs& a) {
         float mm1 = __builtin_inff(), mm2 = __builtin_inff();
         uint32_t S = 0, pend = 0;
         static_for<ncore>([&](auto jc) {
@@ -449,7 +510,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
             f32_to_byte<ce & 3>(st.rm[ce >> 2], r);
             const float v = tj + r;
             t[j] = v; // kept for the mirror pass
-            *reinterpret_cast<float*>(lds + R[G::ridx(P)] + G::col(e0 + j) * G::CS + G::roff(P)) = v;
+            *reinterpret_cast<float*>(lds + R[G::pb(G::col(e0 + j), P)] + G::po(G::col(e0 + j), P)) = v;
         });
     }
 
@@ -458,38 +519,52 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
     //   wave (NWV-ka)  : its run started in block 0                                -> twin at RB + off
     // With every layer active (FULL) the next reader of the column is known at compile time and only the
     // twin it will actually read is written (Z64::twin_a/twin_b); with pruned layers both are.
-    template <int WV> __device__ __forceinline__ void twins(char* lds, uint32_t RA, uint32_t RB) const {
+    // nl: the run-time layer count (read only by the builds with G::RT, Z64::twin_mode_a / _b)
+    template <int WV> __device__ __forceinline__ void twins(char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t RA, uint32_t RB, int nl) const {
         static_for<ncore>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int P = G::shift(e0 + j);
             constexpr int ka = P / G::BLK;
-            constexpr int off = G::col(e0 + j) * G::CS + G::roff(P);
+            constexpr int off = G::col(e0 + j) * G::CS + G::roff(P);                     // block geometry: from RA / RB
+            constexpr int pbi = G::pb(G::col(e0 + j), P), poi = G::po(G::col(e0 + j), P); // packed geometry: the word NROWP below / above
+            constexpr int MA = LayerZ64::owned(j) ? G::twin_mode_a(e0 + j, FULL) : G::TW_NEVER;
+            constexpr int MB = LayerZ64::owned(j) ? G::twin_mode_b(e0 + j, FULL) : G::TW_NEVER;
+            constexpr int TL = G::twin_last_row(e0 + j);
             if constexpr (G::PACKED) {
                 // WV = row wave; lane T of it is the first whose row wrapped into the mirror (ring position z + P >= Z)
                 constexpr int T = (ZC - P) * G::PW - 64 * WV;
-                if constexpr (LayerZ64::owned(j) && G::twin_a(e0 + j, FULL) && T < 64) { // wrapped rows: mirror -> ring
-                    if constexpr (T <= 0) {
-                        *reinterpret_cast<float*>(lds + RA + off) = t[j];
-                    } else {
-                        if (NRLDPC_LANE_GE(T)) *reinterpret_cast<float*>(lds + RA + off) = t[j];
+                if constexpr (MA != G::TW_NEVER && T < 64) { // wrapped rows: mirror -> ring
+                    if (MA == G::TW_ALWAYS || nl <= TL) {
+                        if constexpr (T <= 0) {
+                            *reinterpret_cast<float*>(lds + R[pbi] + (poi - 4 * G::NROWP)) = t[j];
+                        } else {
+                            if (NRLDPC_LANE_GE(T)) *reinterpret_cast<float*>(lds + R[pbi] + (poi - 4 * G::NROWP)) = t[j];
+                        }
                     }
                 }
-                if constexpr (LayerZ64::owned(j) && G::twin_b(e0 + j, FULL) && T > 0) { // the other rows: ring -> mirror
-                    if constexpr (T >= 64) {
-                        *reinterpret_cast<float*>(lds + RB + off) = t[j];
-                    } else {
-                        if (!NRLDPC_LANE_GE(T)) *reinterpret_cast<float*>(lds + RB + off) = t[j];
+                if constexpr (MB != G::TW_NEVER && T > 0) { // the other rows: ring -> mirror
+                    if (MB == G::TW_ALWAYS || nl <= TL) {
+                        if constexpr (T >= 64) {
+                            *reinterpret_cast<float*>(lds + R[pbi] + (poi + 4 * G::NROWP)) = t[j];
+                        } else {
+                            if (!NRLDPC_LANE_GE(T)) *reinterpret_cast<float*>(lds + R[pbi] + (poi + 4 * G::NROWP)) = t[j];
+                        }
                     }
                 }
-            } else if constexpr (LayerZ64::owned(j) && ((G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV) ||
-                                                 (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV))) {
-                if constexpr (G::twin_a(e0 + j, FULL) && WV == (2 * G::NWV - 1 - ka) % G::NWV)
-                    *reinterpret_cast<float*>(lds + RA + off) = t[j];
-                if constexpr (G::twin_b(e0 + j, FULL) && WV == (G::NWV - ka) % G::NWV)
-                    *reinterpret_cast<float*>(lds + RB + off) = t[j];
-                // A unique (empty) asm per store: without it SimplifyCFG sinks the six per-wave store
-                // sequences into one store that indexes t[] dynamically, which pushes t[] to scratch.
-                asm volatile("; twin L%c0 e%c1 w%c2" ::"i"(L), "i"(j), "i"(WV));
+            } else {
+                constexpr bool DA = MA != G::TW_NEVER && WV == (2 * G::NWV - 1 - ka) % G::NWV;
+                constexpr bool DB = MB != G::TW_NEVER && WV == (G::NWV - ka) % G::NWV;
+                if constexpr (DA || DB) {
+                    if constexpr (DA) {
+                        if (MA == G::TW_ALWAYS || nl <= TL) *reinterpret_cast<float*>(lds + RA + off) = t[j];
+                    }
+                    if constexpr (DB) {
+                        if (MB == G::TW_ALWAYS || nl <= TL) *reinterpret_cast<float*>(lds + RB + off) = t[j];
+                    }
+                    // A unique (empty) asm per store: without it SimplifyCFG sinks the six per-wave store
+                    // sequences into one store that indexes t[] dynamically, which pushes t[] to scratch.
+                    asm volatile("; twin L%c0 e%c1 w%c2" ::"i"(L), "i"(j), "i"(WV));
+                }
             }
         });
     }
@@ -513,7 +588,7 @@ template <int BG, int ZC, int L, bool FULL, int NL = BGT<BG>::ROWS, int H = -1> 
 
 // Layers GS..GE (a column-disjoint barrier group, see LayerGroups) processed as one block of code.
 template <int BG, int ZC, int GS, int GE, bool FULL, bool PLAIN>
-__device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA,
+__device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t RA,
                                           uint32_t RB, int w, const DecArgs& a, uint32_t& esign_lo,
                                           uint32_t& esign_hi, float* app_ext) {
     constexpr int N = GE - GS + 1;
@@ -530,9 +605,9 @@ __device__ __forceinline__ void group_z64(DecState<BG>& st, char* lds, const uin
     if constexpr (N > 2) l2.update(st, lds, R, a);
     dispatch_w<0, NWV>(w, [&](auto wc) {
         constexpr int WV = decltype(wc)::value;
-        l0.template twins<WV>(lds, RA, RB);
-        if constexpr (N > 1) l1.template twins<WV>(lds, RA, RB);
-        if constexpr (N > 2) l2.template twins<WV>(lds, RA, RB);
+        l0.template twins<WV>(lds, R, RA, RB, a.n_layers);
+        if constexpr (N > 1) l1.template twins<WV>(lds, R, RA, RB, a.n_layers);
+        if constexpr (N > 2) l2.template twins<WV>(lds, R, RA, RB, a.n_layers);
     });
     if constexpr (!PLAIN) if (a.need_ext) {
         l0.ext(a, esign_lo, esign_hi, app_ext);
@@ -564,7 +639,7 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct Gro
     std::conditional_t<(N > 1), LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true, NL, H>, NoLayer> l1;
     std::conditional_t<(N > 2), LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true, NL, H>, NoLayer> l2;
 
-    template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[z64_nwv(ZC)]) {
+    template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE]) {
         l0.template load_part<LATE>(lds, R);
         if constexpr (N > 1) l1.template load_part<LATE>(lds, R);
         if constexpr (N > 2) l2.template load_part<LATE>(lds, R);
@@ -574,7 +649,7 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct Gro
         if constexpr (N > 1) l1.template track_part<LATE, XF>(st, cap);
         if constexpr (N > 2) l2.template track_part<LATE, XF>(st, cap);
     }
-    template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)], const DecArgs& a) {
+    template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], const DecArgs& a) {
         l0.finish(st, lds, R, a);
         if constexpr (N > 1) l1.finish(st, lds, R, a);
         if constexpr (N > 2) l2.finish(st, lds, R, a);
@@ -585,12 +660,12 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct Gro
         if constexpr (N > 2) l2.ext(a, esign_lo, esign_hi, nullptr);
     }
     // w: the wave's index within its codeword (block geometry) / its row-wave index (packed geometry)
-    __device__ __forceinline__ void twins(char* lds, uint32_t RA, uint32_t RB, int w) const {
+    __device__ __forceinline__ void twins(char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t RA, uint32_t RB, int w, int nl) const {
         dispatch_w<0, (z64_packed(ZC) ? z64p_rw(BG, ZC) : z64_nwv(ZC))>(w, [&](auto wc) {
             constexpr int WV = decltype(wc)::value;
-            l0.template twins<WV>(lds, RA, RB);
-            if constexpr (N > 1) l1.template twins<WV>(lds, RA, RB);
-            if constexpr (N > 2) l2.template twins<WV>(lds, RA, RB);
+            l0.template twins<WV>(lds, R, RA, RB, nl);
+            if constexpr (N > 1) l1.template twins<WV>(lds, R, RA, RB, nl);
+            if constexpr (N > 2) l2.template twins<WV>(lds, R, RA, RB, nl);
         });
     }
 };
@@ -602,10 +677,13 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct Gro
 // early-termination kernel needs it).
 template <int BG, int ZC, int GI, bool ET = false, int NL = BGT<BG>::ROWS, bool XF = false>
 __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, GroupZ64<BG, ZC, 0, NL>& next0, DecState<BG>& st,
-                                             char* lds, const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB,
+                                             char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t RA, uint32_t RB,
                                              int w, const DecArgs& a, float cap, uint32_t& esign_lo,
                                              uint32_t& esign_hi) {
-    constexpr int NG = LayerGroups<BG, NL>::ngroups();
+    using LG = LGof<BG, ZC, NL, -1>;
+    constexpr int NG = LG::ngroups();
+    constexpr bool RT = NL == NL_RT; // run-time layer count: the iteration ends after the last active layer (the kernel prepares group 0)
+    static_assert(!RT || !NRLDPC_Z64_POSTBAR, "the run-time layer count is built for the shipped schedule only");
     // ends group GI-1.  With early termination the parity pass between two iterations ends with a barrier of its own (and the
     // first iteration follows the prologue's), so group 0 needs none -- the waves that only keep the barrier count skip it too.
     if constexpr (!(ET && GI == 0)) __syncthreads();
@@ -621,7 +699,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
         GroupZ64<BG, ZC, GI + 1, NL> nxt;
         nxt.template loads<false>(lds, R);
         cur.finish(st, lds, R, a);
-        cur.twins(lds, RA, RB, w);
+        cur.twins(lds, R, RA, RB, w, launder(a.n_layers));
         if constexpr (ET) {
             cur.ext(a, esign_lo, esign_hi);
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
@@ -630,7 +708,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
     } else {
         next0.template loads<false>(lds, R);
         cur.finish(st, lds, R, a);
-        cur.twins(lds, RA, RB, w);
+        cur.twins(lds, R, RA, RB, w, launder(a.n_layers));
         if constexpr (ET) {
             cur.ext(a, esign_lo, esign_hi);
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
@@ -644,7 +722,7 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
         nxt.template loads<false>(lds, R); // columns untouched by group GI: safe before its writes
         cur.template track<true, XF>(st, cap);
         cur.finish(st, lds, R, a);
-        cur.twins(lds, RA, RB, w);
+        cur.twins(lds, R, RA, RB, w, launder(a.n_layers));
         __builtin_amdgcn_s_setprio(0); // the next group's early part only fills gaps
         if constexpr (ET) {
             cur.ext(a, esign_lo, esign_hi);
@@ -653,24 +731,27 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
         }
         nxt.template track<false, XF>(st, cap);
-        pipeline_z64<BG, ZC, GI + 1, ET, NL, XF>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+        // (run-time layer count: when layer GI was the last active one, the early part above was speculative -- reads of valid
+        // LDS words into registers nobody uses -- and the iteration ends here)
+        if (!RT || LG::group_first(GI + 1) < launder(a.n_layers))
+            pipeline_z64<BG, ZC, GI + 1, ET, NL, XF>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
     } else {
-        next0.template loads<false>(lds, R);
+        if constexpr (!RT) next0.template loads<false>(lds, R);
         cur.template track<true, XF>(st, cap);
         cur.finish(st, lds, R, a);
-        cur.twins(lds, RA, RB, w);
+        cur.twins(lds, R, RA, RB, w, launder(a.n_layers));
         __builtin_amdgcn_s_setprio(0); // the next group's early part only fills gaps
         if constexpr (ET) {
             cur.ext(a, esign_lo, esign_hi);
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
         }
-        next0.template track<false, XF>(st, cap);
+        if constexpr (!RT) next0.template track<false, XF>(st, cap);
     }
 #endif
 }
 
 template <int BG, int ZC, int L>
-__device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R)[z64_nwv(ZC)], uint32_t esign_lo,
+__device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t esign_lo,
                                                    uint32_t esign_hi) {
     using G = Z64<BG, ZC>;
     constexpr int e0 = G::row_ptr(L);
@@ -682,7 +763,7 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
         constexpr int j = decltype(jc)::value;
         constexpr int c = G::col(e0 + j);
         constexpr int P = G::shift(e0 + j);
-        p ^= fbits(*reinterpret_cast<const float*>(lds + R[G::ridx(P)] + c * G::CS + G::roff(P)));
+        p ^= fbits(*reinterpret_cast<const float*>(lds + R[G::pb(c, P)] + G::po(c, P)));
     });
     p >>= 31;
     if constexpr (HAS_EXT) p ^= (L - 4 < 32 ? esign_lo >> ((L - 4) & 31) : esign_hi >> ((L - 36) & 31)) & 1u;
@@ -709,7 +790,20 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
     static_assert(!ETP || (FULL && !PLAIN), "ETP implies FULL and excludes PLAIN");
     static_assert(FULL || NL == BGT<BG>::ROWS, "a run-time layer count uses the all-rows tables");
     using G = Z64<BG, ZC, NCWG, NL>;
-    using LGN = LayerGroups<BG, NL>;
+    using LGN = LGof<BG, ZC, NL, -1>;
+    constexpr bool RT = NL == NL_RT; // FULL with the layer count as a run-time prefix of the all-rows tables
+    static_assert(!RT || FULL, "a run-time layer count is a mode of the pipelined builds");
+    // barriers a wave without a codeword keeps per iteration: one per group with an active layer
+    auto idle_barriers = [&](int skip) {
+        if constexpr (RT) {
+            static_for<LGN::ngroups()>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (g >= skip && LGN::group_first(g) < launder(a.n_layers)) __syncthreads();
+            });
+        } else {
+            for (int g = skip; g < LGN::ngroups(); ++g) __syncthreads();
+        }
+    };
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -759,7 +853,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         const bool wide = (reinterpret_cast<uintptr_t>(a.llr) & 15) == 0;
         // The extension-parity LLR of a pruned row is never used (only soft output echoes it): at R = 8/9
         // that is 41 of 68 columns of HBM input saved.  Blocks of 8 rows, wave-uniform branches.
-        const int next_used = a.app ? G::NEXT : FULL ? NL - 4 : launder(a.n_layers) - 4;
+        const int next_used = a.app ? G::NEXT : (FULL && !RT) ? NL - 4 : launder(a.n_layers) - 4;
         auto ingest_as = [&](auto kind_c) {
             constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
             auto raw = [&](size_t i) -> uint32_t { // one LLR, raw bits
@@ -875,11 +969,14 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             for (int it = 1; it <= a.max_iter; ++it) {
                 GroupZ64<BG, ZC, 0, NL> nx;
                 pipeline_z64<BG, ZC, 0, false, NL, XF>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
+                if constexpr (RT) { // wherever the iteration ended: group 0's early part (none of its edges is early here)
+                    nx.template loads<false>(lds, R);
+                    nx.template track<false, XF>(st, cap);
+                }
                 g0 = nx;
             }
         } else {
-            for (int it = 1; it <= a.max_iter; ++it)
-                for (int g = 0; g < LGN::ngroups(); ++g) __syncthreads();
+            for (int it = 1; it <= a.max_iter; ++it) idle_barriers(0);
         }
         __syncthreads();
     }
@@ -900,7 +997,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
                 static_for<PO.n>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int L = PO.v[i];
-                    if (!stop) {
+                    if (!stop && (!RT || L < launder(a.n_layers))) {
                         bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
                         if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n) stop = __any((int)bad) != 0;
                     }
@@ -945,6 +1042,10 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
                 esign_lo = 0; esign_hi = 0;
                 GroupZ64<BG, ZC, 0, NL> nx;
                 pipeline_z64<BG, ZC, 0, true, NL>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
+                if constexpr (RT) {
+                    nx.template loads<false>(lds, R);
+                    nx.template track<false>(st, cap);
+                }
                 g0 = nx;
                 all_done = parity_pass(it);
                 if (all_done || done) { ++it; break; }
@@ -953,7 +1054,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         if (!all_done) {
             done = true;
             for (; it <= a.max_iter; ++it) {
-                for (int g = 0; g < LGN::ngroups() - 1; ++g) __syncthreads(); // (see pipeline_z64: group 0 has no barrier here)
+                idle_barriers(1); // (see pipeline_z64: group 0 has no barrier here)
                 if (parity_pass(it)) break;
             }
         }
@@ -1112,7 +1213,19 @@ template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& 
         NRLDPC_Z64_NL_LIST(NRLDPC_Z64_NL_CASE)
 #undef NRLDPC_Z64_NL_CASE
     }
-    // other pruned layer counts and soft output (a test / debug feature) share the unpipelined general kernel
+    // every other pruned layer count: the same pipelined / split kernels with the layer count as a run-time prefix of the
+    // all-rows tables (NL_RT); NRLDPC_NO_RT=1 sends them to the general kernel instead (A/B)
+    static const bool no_rt = getenv("NRLDPC_NO_RT") != nullptr;
+    if (a.n_layers != ROWS && !a.app && !no_rt) {
+        if constexpr (z64_has_split<BG, ZC, ROWS>()) {
+            if (use_split<BG, ZC, ROWS>()) return a.early_term ? launch_z64s<BG, ZC, true, NL_RT>(a, s) : launch_z64s<BG, ZC, false, NL_RT>(a, s);
+        }
+        if constexpr (z64_has_row<BG, ZC, ROWS>()) {
+            if (a.early_term) return launch_z64f<BG, ZC, z64_ncwg_et<BG, ZC>(), true, false, true, NL_RT>(a, s);
+            return launch_z64f<BG, ZC, NCWG, true, true, false, NL_RT>(a, s);
+        }
+    }
+    // soft output (a test / debug feature) and what is left of the pruned layer counts: the unpipelined general kernel
     if (a.n_layers != ROWS || a.app) return launch_z64f<BG, ZC, NCWG, false, false>(a, s);
     if constexpr (z64_has_row<BG, ZC, ROWS>()) {
         if (a.early_term) return launch_z64f<BG, ZC, z64_ncwg_et<BG, ZC>(), true, false, true>(a, s);

@@ -22,7 +22,7 @@ template <int BG, int ZC, int NL = BGT<BG>::ROWS> struct Z64P : Z64<BG, ZC, 1, N
     static constexpr int NROW = ZC * NCW;        // row lanes in use (of 64 RW)
     static constexpr int THREADS = 2 * RW * 64;
     static_assert(NCW >= 1 && NROW <= 64 * RW && 64 * RW - NROW < 64 && NCW + 1 <= NROW && 2 * RW <= 16, "packed workgroup shape");
-    static_assert((B::NC - 1) * B::CS + 4 * (2 * ZC - 1) * NCW < 65536, "LDS immediate offsets");
+    static_assert(B::NROWP == NROW && B::po(B::NC - 1, ZC - 1) + 4 * NROW < 65536 && B::po(B::HICOL < B::NC ? B::HICOL : 0, 0) - 4 * NROW >= 0, "LDS immediate offsets");
     static constexpr size_t FLAGS = (size_t)B::GUARD + B::CWS; // [guard][NC columns of ring | mirror][flags]
     static constexpr size_t lds_bytes() { return FLAGS + 4 * (size_t)((NCW + 1 + 3) / 4 * 4); }
 };
@@ -58,8 +58,16 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
     constexpr int V = z64s_variant<BG, ZC, NL>();
     static_assert((V & SPLIT_DUAL) == 0, "no dual rows in the packed geometry");
 
-    uint32_t R[1] = {(uint32_t)G::GUARD + 4u * (uint32_t)g};
-    const uint32_t RA = R[0] - 4u * (uint32_t)G::NROW, RB = R[0] + 4u * (uint32_t)G::NROW;
+    // base registers of the edge addresses (Z64::pb / po): the thread's word of the guard in front of column 0 [and the same HIOFF
+    // bytes further for the columns an immediate offset from R[0] does not reach]; opaque, so that the compiler keeps them as they are
+    uint32_t R[G::NBASE];
+    R[0] = 4u * (uint32_t)g;
+    if constexpr (G::NBASE > 1) {
+        R[1] = R[0] + (uint32_t)G::HIOFF;
+        asm volatile("" : "+v"(R[1]));
+    }
+    constexpr uint32_t RA = 0, RB = 0;                           // (the block geometry's twin bases: unused here)
+    const uint32_t home0 = (uint32_t)G::GUARD + 4u * (uint32_t)g; // this thread's word of column 0's ring
     const size_t base = (size_t)(present ? cw : 0) * ncwz;
 
     // ---- core columns -> LDS (ring and mirror), the halves take alternate columns; raw bits first, conversions after
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                     if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)x[k]));
                     else v = __uint_as_float(x[k]);
                     const float q = present ? ingest(v, a.scale, true) : 0.0f;
-                    char* home = lds + R[0] + col * G::CS;
+                    char* home = lds + home0 + col * G::CS;
                     *reinterpret_cast<float*>(home) = q;
                     *reinterpret_cast<float*>(home + 4 * G::NROW) = q;
                 }
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
             constexpr int k = decltype(kc)::value;
             const int col = 2 * k + half;
             if (2 * k + 1 < G::KB || col < G::KB)
-                hard[(size_t)col * ZC] = *reinterpret_cast<const float*>(lds + R[0] + col * G::CS) < 0.0f ? 1 : 0;
+                hard[(size_t)col * ZC] = *reinterpret_cast<const float*>(lds + home0 + col * G::CS) < 0.0f ? 1 : 0;
         });
         if (a.iters && z == 0 && half == 0) a.iters[cw] = it;
     };
@@ -118,17 +126,23 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
         auto load_ext = [&](auto kind_c) {
             constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
             uint32_t xe[O::NEXT > 0 ? O::NEXT : 1];
-            static_for<NL - 4>([&](auto ic) {
-                constexpr int L = 4 + decltype(ic)::value;
-                if constexpr (O::mine(L)) {
-                    constexpr int xi = O::ext_index(L);
-                    const size_t i = base + (size_t)(G::NC + L - 4) * ZC + z;
-                    xe[xi] = 0u;
-                    if (present) {
-                        if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
-                        else xe[xi] = static_cast<const uint32_t*>(a.llr)[i];
+            // (run-time layer count: pruned rows' extension LLRs are never used and never loaded, in blocks of 8 rows)
+            static_for<(G::NLT - 4 + 7) / 8>([&](auto bc) {
+                constexpr int L0 = 4 + 8 * decltype(bc)::value;
+                constexpr int L1 = L0 + 8 < G::NLT ? L0 + 8 : G::NLT;
+                const bool used = present && (!G::RT || L0 < launder(a.n_layers));
+                static_for<L1 - L0>([&](auto ic) {
+                    constexpr int L = L0 + decltype(ic)::value;
+                    if constexpr (O::mine(L)) {
+                        constexpr int xi = O::ext_index(L);
+                        const size_t i = base + (size_t)(G::NC + L - 4) * ZC + z;
+                        xe[xi] = 0u;
+                        if (used) {
+                            if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
+                            else xe[xi] = static_cast<const uint32_t*>(a.llr)[i];
+                        }
                     }
-                }
+                });
             });
             static_for<O::NEXT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -159,6 +173,10 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
             if constexpr (H == 0) {
                 GroupZ64<BG, ZC, 0, NL, H> nx;
                 s_crit<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, rw, av, cap, esign_lo, esign_hi);
+                if constexpr (G::RT) { // wherever the iteration ended: group 0's early part (see the block geometry's split kernel)
+                    nx.template loads<false>(lds, R);
+                    nx.template track<false, XF>(st, cap);
+                }
                 g0 = nx;
             } else {
                 s_early<BG, ZC, NL, H, ETP, XF, 0>(g0, st, lds, R, RA, RB, rw, av, cap, esign_lo, esign_hi);
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                 static_for<PO.n>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int L = PO.v[i];
-                    if (!stop) {
+                    if (!stop && (!G::RT || L < launder(a.n_layers))) {
                         bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
                         if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n || O::ncore(L) > 10 || (i + 1 < PO.n && O::ncore(PO.v[i + 1 < PO.n ? i + 1 : i]) > 10)) {
                             if (bad && !done) flags[c] = 1;
@@ -249,8 +267,16 @@ __global__ __launch_bounds__(z64p_rw(BG, ZC) * 64, (z64pg_wpe<BG, ZC>())) void n
     const bool present = cw < a.batch;
     int* flags = reinterpret_cast<int*>(lds + G::FLAGS);
     constexpr size_t ncwz = (size_t)G::COLS * ZC;
-    uint32_t R[1] = {(uint32_t)G::GUARD + 4u * (uint32_t)g};
-    const uint32_t RA = R[0] - 4u * (uint32_t)G::NROW, RB = R[0] + 4u * (uint32_t)G::NROW;
+    // base registers of the edge addresses (Z64::pb / po): the thread's word of the guard in front of column 0 [and the same HIOFF
+    // bytes further for the columns an immediate offset from R[0] does not reach]; opaque, so that the compiler keeps them as they are
+    uint32_t R[G::NBASE];
+    R[0] = 4u * (uint32_t)g;
+    if constexpr (G::NBASE > 1) {
+        R[1] = R[0] + (uint32_t)G::HIOFF;
+        asm volatile("" : "+v"(R[1]));
+    }
+    constexpr uint32_t RA = 0, RB = 0;                           // (the block geometry's twin bases: unused here)
+    const uint32_t home0 = (uint32_t)G::GUARD + 4u * (uint32_t)g; // this thread's word of column 0's ring
     const size_t base = (size_t)(present ? cw : 0) * ncwz;
     float* app_row = (present && a.app) ? a.app + base + z : nullptr;
 
@@ -292,7 +318,7 @@ __global__ __launch_bounds__(z64p_rw(BG, ZC) * 64, (z64pg_wpe<BG, ZC>())) void n
             static_for<G::NC>([&](auto cc) {
                 constexpr int col = decltype(cc)::value;
                 const float q = present ? ingest(val(x[col]), a.scale, true) : 0.0f;
-                char* home = lds + R[0] + col * G::CS;
+                char* home = lds + home0 + col * G::CS;
                 *reinterpret_cast<float*>(home) = q;
                 *reinterpret_cast<float*>(home + 4 * G::NROW) = q;
             });
@@ -316,7 +342,7 @@ __global__ __launch_bounds__(z64p_rw(BG, ZC) * 64, (z64pg_wpe<BG, ZC>())) void n
         uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * ZC) + z;
         static_for<G::NC>([&](auto cc) {
             constexpr int col = decltype(cc)::value;
-            const float v = *reinterpret_cast<const float*>(lds + R[0] + col * G::CS);
+            const float v = *reinterpret_cast<const float*>(lds + home0 + col * G::CS);
             if constexpr (col < G::KB) hard[(size_t)col * ZC] = v < 0.0f ? 1 : 0;
             if (app_row) app_row[(size_t)col * ZC] = v * a.inv_scale;
         });
@@ -401,6 +427,11 @@ template <int BG, int ZC, int NL> static hipError_t launch_z64p_pruned(const Dec
     return a.early_term ? launch_z64p_t<BG, ZC, true, NL>(a, s) : launch_z64p_t<BG, ZC, false, NL>(a, s);
 }
 template <int BG, int ZC> static hipError_t launch_z64p(const DecArgs& a, hipStream_t s) {
+    if (a.n_layers != BGT<BG>::ROWS) { // a pruned layer count without a build of its own: the run-time-prefix kernels (NL_RT)
+        if (!a.early_term) return launch_z64p_t<BG, ZC, false, NL_RT>(a, s);
+        if constexpr (z64p_not_et<BG, ZC>()) return hipErrorInvalidValue; // not reached
+        else return launch_z64p_t<BG, ZC, true, NL_RT>(a, s);
+    }
     if (!a.early_term) return launch_z64p_t<BG, ZC, false>(a, s);
     if constexpr (z64p_not_et<BG, ZC>()) return hipErrorInvalidValue; // not reached: launch_decode asks has_z64p_kernel first
     else return launch_z64p_t<BG, ZC, true>(a, s);

@@ -32,6 +32,15 @@ namespace nrldpc {
 #ifndef NRLDPC_Z64S_PRIO
 #define NRLDPC_Z64S_PRIO 2
 #endif
+// The hand-over between the halves.  -DNRLDPC_EXP_NOBARRIER=1 builds a TIMING-ONLY kernel (results wrong): the workgroup
+// barriers of the iteration loop become a wait for the wave's own LDS operations, which bounds what any finer-grained
+// synchronisation (per-column flags between the waves that share a ring segment) could return
+// (profiles/r04_headline_nobarrier.txt).
+#if defined(NRLDPC_EXP_NOBARRIER) && NRLDPC_EXP_NOBARRIER == 1
+#define NRLDPC_Z64S_HANDOVER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define NRLDPC_Z64S_HANDOVER() __syncthreads()
+#endif
 
 template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
     using B = Z64<BG, ZC, 1, NL>;
@@ -40,7 +49,7 @@ template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
     static constexpr bool usable() { return THREADS <= 1024 && NG >= 2; }
     // rings + trailing guard + flags [+ the extension-column channel LLRs, one int8 per extension row and row-thread]
     static constexpr size_t XOFF = (size_t)B::CWS + B::GUARD + 16;
-    static constexpr size_t XBYTES = (size_t)(NL - 4) * ZC;
+    static constexpr size_t XBYTES = (size_t)(B::NLT - 4) * ZC;
     // Workgroups a CU holds: 24 wave slots at the 80-VGPR budget, 160 KB of LDS.  The extension LLRs move from 6 registers
     // per thread into LDS exactly where that does not cost a workgroup (Z = 384, 288, 256, 240 ... : the wave slots bind;
     // Z <= 192 with 2- to 6-wave workgroups: LDS binds, and one workgroup fewer per CU costs 4-8 %, measured).
@@ -63,31 +72,35 @@ template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
 };
 
 template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
-__device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)],
+__device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE],
                                         uint32_t RA, uint32_t RB, int w, const DecArgs& a, float cap, uint32_t& esign_lo,
                                         uint32_t& esign_hi);
 
 // interval GI, this half owns group GI: `cur` arrives with its early part done
 template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
 __device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds,
-                                       const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
+                                       const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
                                        float cap, uint32_t& esign_lo, uint32_t& esign_hi) {
-    constexpr int NG = LGof<BG, ZC, NL, 0>::ngroups();
+    using LG = LGof<BG, ZC, NL, 0>;
+    constexpr int NG = LG::ngroups();
+    constexpr bool RT = NL == NL_RT; // run-time layer count: the iteration ends after the last active layer's group (the kernel prepares group 0)
     // ends interval GI-1: group GI-1's writes are visible.  With early termination the parity pass between two iterations
     // ends with a barrier of its own (and the first iteration follows the prologue's), so interval 0 needs none.
-    if constexpr (!(ET && GI == 0)) __syncthreads();
+    if constexpr (!(ET && GI == 0)) NRLDPC_Z64S_HANDOVER();
     __builtin_amdgcn_s_setprio(NRLDPC_Z64S_PRIO); // the next barrier waits for this half
     cur.template loads<true>(lds, R);
     cur.template track<true, XF>(st, cap);
     cur.finish(st, lds, R, a);
-    cur.twins(lds, RA, RB, w);
+    cur.twins(lds, R, RA, RB, w, launder(a.n_layers));
     __builtin_amdgcn_s_setprio(0);
     if constexpr (ET) {
         cur.ext(a, esign_lo, esign_hi);
         asm volatile("" : "+v"(esign_lo), "+v"(esign_hi)); // see pipeline_z64
     }
     if constexpr (GI + 1 < NG) {
-        s_early<BG, ZC, NL, H, ET, XF, GI + 1>(next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+        if (!RT || LG::group_first(GI + 1) < launder(a.n_layers))
+            s_early<BG, ZC, NL, H, ET, XF, GI + 1>(next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+    } else if constexpr (RT) {
     } else if constexpr (H == 0 || Own<BG, NL, H, z64s_variant<BG, ZC, NL>()>::dual(0)) { // (a dual row 0: both halves prepare their own edges of it)
         // odd group count: this half owns the last group AND group 0, whose early part it runs right here (the one
         // interval per iteration that is software-pipelined within a wave, as in pipeline_z64)
@@ -98,16 +111,21 @@ __device__ __forceinline__ void s_crit(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ6
 
 // interval GI, the other half owns group GI: this half prepares group GI+1 (cyclically: group 0 of the next iteration)
 template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
-__device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds, const uint32_t (&R)[z64_nwv(ZC)],
+__device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE],
                                         uint32_t RA, uint32_t RB, int w, const DecArgs& a, float cap, uint32_t& esign_lo,
                                         uint32_t& esign_hi) {
-    constexpr int NG = LGof<BG, ZC, NL, 0>::ngroups();
-    if constexpr (!(ET && GI == 0)) __syncthreads(); // see s_crit
+    using LG = LGof<BG, ZC, NL, 0>;
+    constexpr int NG = LG::ngroups();
+    constexpr bool RT = NL == NL_RT; // see s_crit
+    if constexpr (!(ET && GI == 0)) NRLDPC_Z64S_HANDOVER(); // see s_crit
     if constexpr (GI + 1 < NG) {
-        GroupZ64<BG, ZC, GI + 1, NL, H> nxt;
-        nxt.template loads<false>(lds, R); // columns group GI does not write
-        nxt.template track<false, XF>(st, cap);
-        s_crit<BG, ZC, NL, H, ET, XF, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+        if (!RT || LG::group_first(GI + 1) < launder(a.n_layers)) {
+            GroupZ64<BG, ZC, GI + 1, NL, H> nxt;
+            nxt.template loads<false>(lds, R); // columns group GI does not write
+            nxt.template track<false, XF>(st, cap);
+            s_crit<BG, ZC, NL, H, ET, XF, GI + 1>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
+        }
+    } else if constexpr (RT) {
     } else if constexpr (H == 0 || Own<BG, NL, H, z64s_variant<BG, ZC, NL>()>::dual(0)) { // even group count: the last group is the other half's, group 0 is this one's
         next0.template loads<false>(lds, R);
         next0.template track<false, XF>(st, cap);
@@ -118,24 +136,26 @@ __device__ __forceinline__ void s_early(GroupZ64<BG, ZC, 0, NL, H>& next0, St& s
 // edges done.  Two barriers: the usual one in front of the group, and one between the halves' partial searches and pass 2.
 template <int BG, int ZC, int NL, int H, bool ET, bool XF, int GI, class St>
 __device__ __forceinline__ void s_dense(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ64<BG, ZC, 0, NL, H>& next0, St& st, char* lds,
-                                        const uint32_t (&R)[z64_nwv(ZC)], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
+                                        const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t RA, uint32_t RB, int w, const DecArgs& a,
                                         float cap, uint32_t& esign_lo, uint32_t& esign_hi, uint32_t xmine, uint32_t xother) {
     using O = Own<BG, NL, H, z64s_variant<BG, ZC, NL>()>;
     using LG = LGof<BG, ZC, NL, 0>;
     constexpr int NG = LG::ngroups();
+    constexpr bool RT = NL == NL_RT; // see s_crit (the dual rows 0..3 themselves are always active)
     static_assert(LG::group_last(LG::group_first(GI)) == LG::group_first(GI), "a dual row is a barrier group of its own");
-    if constexpr (!(ET && GI == 0)) __syncthreads(); // see s_crit
+    if constexpr (!(ET && GI == 0)) NRLDPC_Z64S_HANDOVER(); // see s_crit
     __builtin_amdgcn_s_setprio(NRLDPC_Z64S_PRIO);
     cur.template loads<true>(lds, R);
     cur.template track<true, XF>(st, cap);
     cur.l0.publish(lds, xmine);
-    __syncthreads();
+    NRLDPC_Z64S_HANDOVER();
     cur.l0.merge(lds, xother);
     cur.finish(st, lds, R, a);
-    cur.twins(lds, RA, RB, w);
+    cur.twins(lds, R, RA, RB, w, launder(a.n_layers));
     __builtin_amdgcn_s_setprio(0);
     if constexpr (GI + 1 < NG) {
-        if constexpr (O::dual(LG::group_first(GI + 1))) {
+        if (RT && LG::group_first(GI + 1) >= launder(a.n_layers)) {
+        } else if constexpr (O::dual(LG::group_first(GI + 1))) {
             GroupZ64<BG, ZC, GI + 1, NL, H> nxt;
             nxt.template loads<false>(lds, R);
             nxt.template track<false, XF>(st, cap);
@@ -148,7 +168,7 @@ __device__ __forceinline__ void s_dense(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ
         } else {
             s_early<BG, ZC, NL, H, ET, XF, GI + 1>(next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
         }
-    } else { // the dual row was the last group: row 0 (dual as well) follows
+    } else if constexpr (!RT) { // the dual row was the last group: row 0 (dual as well) follows
         next0.template loads<false>(lds, R);
         next0.template track<false, XF>(st, cap);
     }
@@ -272,13 +292,26 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
         auto load_ext = [&](auto kind_c) {
             constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
             uint32_t xe[O::NEXT > 0 ? O::NEXT : 1];
-            static_for<NL - 4>([&](auto ic) {
-                constexpr int L = 4 + decltype(ic)::value;
-                if constexpr (O::mine(L)) {
-                    constexpr int xi = O::ext_index(L);
-                    const size_t i = base + (size_t)(G::NC + L - 4) * ZC + z;
-                    if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
-                    else xe[xi] = static_cast<const uint32_t*>(a.llr)[i];
+            // (run-time layer count: the extension LLR of a pruned row is never used -- blocks of 8 rows behind wave-uniform
+            // branches keep those columns out of the HBM traffic: at R = 8/9 that is 41 of BG1's 68 columns)
+            static_for<(G::NLT - 4 + 7) / 8>([&](auto bc) {
+                constexpr int L0 = 4 + 8 * decltype(bc)::value;
+                constexpr int L1 = L0 + 8 < G::NLT ? L0 + 8 : G::NLT;
+                if (!G::RT || L0 < launder(a.n_layers)) {
+                    static_for<L1 - L0>([&](auto ic) {
+                        constexpr int L = L0 + decltype(ic)::value;
+                        if constexpr (O::mine(L)) {
+                            constexpr int xi = O::ext_index(L);
+                            const size_t i = base + (size_t)(G::NC + L - 4) * ZC + z;
+                            if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
+                            else xe[xi] = static_cast<const uint32_t*>(a.llr)[i];
+                        }
+                    });
+                } else {
+                    static_for<L1 - L0>([&](auto ic) {
+                        constexpr int L = L0 + decltype(ic)::value;
+                        if constexpr (O::mine(L)) xe[O::ext_index(L)] = 0u;
+                    });
                 }
             });
             static_for<O::NEXT>([&](auto ic) {
@@ -312,10 +345,18 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
             if constexpr (D0) {
                 GroupZ64<BG, ZC, 0, NL, H> nx;
                 s_dense<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi, xmine, xother);
+                if constexpr (G::RT) { // wherever the iteration ended: group 0's early part (none of its edges is early here)
+                    nx.template loads<false>(lds, R);
+                    nx.template track<false, XF>(st, cap);
+                }
                 g0 = nx;
             } else if constexpr (H == 0) {
                 GroupZ64<BG, ZC, 0, NL, H> nx;
                 s_crit<BG, ZC, NL, H, ETP, XF, 0>(g0, nx, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
+                if constexpr (G::RT) {
+                    nx.template loads<false>(lds, R);
+                    nx.template track<false, XF>(st, cap);
+                }
                 g0 = nx;
             } else {
                 s_early<BG, ZC, NL, H, ETP, XF, 0>(g0, st, lds, R, RA, RB, w, av, cap, esign_lo, esign_hi);
@@ -330,7 +371,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
                 static_for<PO.n>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int L = PO.v[i];
-                    if (!stop) {
+                    if (!stop && (!G::RT || L < launder(a.n_layers))) {
                         bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
                         // (a vote right after every dense row as well: a vote is a point the compiler cannot move loads across,
                         // and 19 + 16 a-posteriori words in flight spill at 80 VGPRs)

@@ -45,8 +45,17 @@ template <int BG> struct BGD : BGT<BG> {
 // SG ("single"): every layer a group of its own -- always legal (a barrier in front of every layer IS the sequential schedule);
 // the split kernels of the 12-wave workgroups use it (z64s_single, nrldpc_decode_z64s.h): their two halves alternate per group,
 // and one-layer groups keep the two halves' shares of every interval closer than the merged pairs do.
-template <int BG, int NL = BGT<BG>::ROWS, bool SG = false> struct LayerGroups {
+//
+// NL == NL_RT: the layer count is a RUN-TIME prefix (DecArgs::n_layers) of the all-rows tables.  Pruning is always a row
+// prefix, so the groups, the ownership of layers by the halves of a split kernel and every message slot are those of the
+// all-rows build; what the kernels of such a build decide at run time is where an iteration ends (scalar branches), and which
+// copy of a ring's block 0 the column's next reader will read when the compile-time next reader may be pruned (LayerZ64::twins).
+constexpr int NL_RT = 0;
+template <int BG> constexpr int nl_rows(int NL) { return NL == NL_RT ? BGT<BG>::ROWS : NL; }
+
+template <int BG, int NL_ = BGT<BG>::ROWS, bool SG = false> struct LayerGroups {
     using G = BGD<BG>;
+    static constexpr int NL = nl_rows<BG>(NL_);
     static_assert(NL >= 4 && NL <= BGT<BG>::ROWS, "active layer count");
     static constexpr unsigned long long colmask(int L) {
         unsigned long long m = 0;
@@ -93,9 +102,10 @@ template <int BG, int NL = BGT<BG>::ROWS, bool SG = false> struct LayerGroups {
 // each holds the messages (and extension LLRs) of every other group only -- about half the registers, twice the waves.
 // V: variant bits of a split kernel (z64s_variant<BG, ZC, NL>()): 1 = dual dense rows, 2 = one-layer barrier groups.
 constexpr int SPLIT_DUAL = 1, SPLIT_SINGLE = 2;
-template <int BG, int NL, int H, int V = 0> struct Own {
+template <int BG, int NL_, int H, int V = 0> struct Own {
     using G = BGD<BG>;
-    using LG = LayerGroups<BG, NL, (H >= 0 && (V & SPLIT_SINGLE) != 0)>;
+    static constexpr int NL = nl_rows<BG>(NL_); // rows the tables cover (NL_RT: all of them)
+    using LG = LayerGroups<BG, NL_, (H >= 0 && (V & SPLIT_SINGLE) != 0)>;
     static constexpr bool mine(int L) { return H < 0 || LG::group_index(L) % 2 == H; }
     static constexpr int ncore(int L) { return G::row_ptr(L + 1) - G::row_ptr(L) - (L >= 4 ? 1 : 0); }
     // "Dual" rows: the dense core rows 0..3 (BG1: 19 edges each, a quarter of all edges, each a barrier group of its own) are

@@ -14,5 +14,8 @@
 // so a batch quantised here decodes bit for bit like the same batch ingested on the device.  Returns true when a -inf
 // was met: int8 has no code left for it, and the caller sends that chunk in its own format instead.
 bool nrldpc_quantise_i8(int8_t* dst, const void* src, size_t n, int src_kind, float scale);
+// the same through one named code path -- 0: plain C++, 1: AVX2 + F16C, 2: AVX-512; -1: the best the CPU has (= the call above) --
+// falling back to the next one down when the CPU lacks it (tests compare the paths with each other)
+bool nrldpc_quantise_i8_path(int8_t* dst, const void* src, size_t n, int src_kind, float scale, int path);
 
 #endif

@@ -210,30 +210,32 @@ int orc_encode(int bg, int Z, const uint8_t* info, int batch, uint8_t* cw) {
 /*   stop     after an iteration if early_term and every parity of the active rows holds        */
 /*   output   hard_k = APP_k < 0 (k < K); app = APP/scale                                      */
 /* ------------------------------------------------------------------------------------------ */
-static int32_t ingest(double llr, int scale, int core) {
+/* qmax: the saturation of channel values and messages in grid units -- ORC_QMAX (127: the int8 grid of the kernels) for the
+ * build algorithm; the "wide" variant (orc_decode_onmsq_wide) takes 32767 to show what the 8-bit grid costs in BLER. */
+static int32_t ingest(double llr, int scale, int core, int qmax) {
     if (llr != llr) return 0;
-    if (isinf(llr)) return core ? (llr > 0 ? ORC_FILL : -ORC_FILL) : (llr > 0 ? ORC_QMAX : -ORC_QMAX);
+    if (isinf(llr)) return core ? (llr > 0 ? ORC_FILL : -ORC_FILL) : (llr > 0 ? qmax : -qmax);
     float x = (float)llr * (float)scale;
-    if (x > (float)ORC_QMAX) x = (float)ORC_QMAX;
-    if (x < -(float)ORC_QMAX) x = -(float)ORC_QMAX;
+    if (x > (float)qmax) x = (float)qmax;
+    if (x < -(float)qmax) x = -(float)qmax;
     return (int32_t)nearbyintf(x);
 }
 
 /* alpha*m - beta is formed exactly (double holds the 24-bit alpha times the <= 21-bit m) and rounded ONCE, to the
  * nearest integer, ties to even; the kernels get the same value from one fp32 fused multiply-add against 2^23 - beta. */
-static int32_t scale_mag(float alpha, float beta, int32_t m) {
+static int32_t scale_mag(float alpha, float beta, int32_t m, int qmax) {
     double f = nearbyint((double)alpha * (double)m - (double)beta);
-    if (f > (double)ORC_QMAX) f = (double)ORC_QMAX;
+    if (f > (double)qmax) f = (double)qmax;
     if (f < 0.0) f = 0.0;
     return (int32_t)f;
 }
 
-static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_term, float alpha, float beta,
-                    const int32_t* q, uint8_t* hard, int32_t* app_q, int8_t* rmsg, int32_t* APP) {
+static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_term, float alpha, float beta, int qmax,
+                    const int32_t* q, uint8_t* hard, int32_t* app_q, int16_t* rmsg, int32_t* APP) {
     const int Z = g->Z;
     const int N = g->ncols * Z;
     memcpy(APP, q, sizeof(int32_t) * (size_t)N);
-    memset(rmsg, 0, (size_t)g->row_ptr[n_layers] * Z);
+    memset(rmsg, 0, sizeof(int16_t) * (size_t)g->row_ptr[n_layers] * Z);
     int it = 0;
     for (it = 1; it <= max_iter; ++it) {
         for (int l = 0; l < n_layers; ++l) {
@@ -251,13 +253,13 @@ static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_te
                     if (a < m1) { m2 = m1; m1 = a; } else if (a < m2) m2 = a;
                     S ^= (t[j] < 0);
                 }
-                const int32_t M1 = scale_mag(alpha, beta, m1), M2 = scale_mag(alpha, beta, m2);
+                const int32_t M1 = scale_mag(alpha, beta, m1, qmax), M2 = scale_mag(alpha, beta, m2, qmax);
                 for (int j = 0; j < deg; ++j) {
                     int32_t a = t[j] < 0 ? -t[j] : t[j];
                     int32_t mag = (a == m1) ? M2 : M1;
                     int32_t r = ((t[j] < 0) ^ S) ? -mag : mag;
                     APP[vi[j]] = t[j] + r;
-                    rmsg[(size_t)(e0 + j) * Z + z] = (int8_t)r;
+                    rmsg[(size_t)(e0 + j) * Z + z] = (int16_t)r;
                 }
             }
         }
@@ -281,8 +283,8 @@ static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_te
 
 /* llr: [batch][ncols*Z] double.  hard: [batch][K] bytes.  iters: [batch] or NULL.
  * app: [batch][ncols*Z] float (APP/scale) or NULL. */
-int orc_decode_onmsq(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, float beta, int scale,
-                     const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
+static int decode_onmsq_q(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, float beta, int scale, int qmax,
+                          const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
     orc_graph g;
     int rc = graph_init(&g, bg, Z);
     if (rc) return rc;
@@ -294,11 +296,11 @@ int orc_decode_onmsq(int bg, int Z, int n_layers, int max_iter, int early_term, 
         int32_t* q = (int32_t*)malloc(sizeof(int32_t) * N);
         int32_t* APP = (int32_t*)malloc(sizeof(int32_t) * N);
         int32_t* aq = (int32_t*)malloc(sizeof(int32_t) * N);
-        int8_t* rm = (int8_t*)malloc((size_t)g.nnz * Z);
+        int16_t* rm = (int16_t*)malloc(sizeof(int16_t) * (size_t)g.nnz * Z);
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < batch; ++b) {
-            for (size_t v = 0; v < N; ++v) q[v] = ingest(llr[b * N + v], scale, (int)(v / Z) < g.kb + 4);
-            int it = nmsq_one(&g, n_layers, max_iter, early_term, alpha, beta, q, hard + b * K, aq, rm, APP);
+            for (size_t v = 0; v < N; ++v) q[v] = ingest(llr[b * N + v], scale, (int)(v / Z) < g.kb + 4, qmax);
+            int it = nmsq_one(&g, n_layers, max_iter, early_term, alpha, beta, qmax, q, hard + b * K, aq, rm, APP);
             if (iters) iters[b] = it;
             if (app)
                 for (size_t v = 0; v < N; ++v) app[b * N + v] = (float)aq[v] / (float)scale;
@@ -306,6 +308,20 @@ int orc_decode_onmsq(int bg, int Z, int n_layers, int max_iter, int early_term, 
         free(q); free(APP); free(aq); free(rm);
     }
     return 0;
+}
+
+int orc_decode_onmsq(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, float beta, int scale,
+                     const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
+    return decode_onmsq_q(bg, Z, n_layers, max_iter, early_term, alpha, beta, scale, ORC_QMAX, llr, batch, hard, iters, app);
+}
+
+/* The same algorithm on a WIDE grid: channel values and messages saturate at +/-qmax grid units (e.g. 32767: 16-bit
+ * messages, no +/-15.9 LLR ingest clamp at scale 8) instead of the kernels' +/-127.  No kernel computes this; it exists to
+ * put a number on what the 8-bit grid costs in dB (tests/test_bler_gap_gpu.py::test_cost_of_the_8_bit_grid). */
+int orc_decode_onmsq_wide(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, float beta, int scale, int qmax,
+                          const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
+    if (qmax < 1 || qmax > 32767) return -4;
+    return decode_onmsq_q(bg, Z, n_layers, max_iter, early_term, alpha, beta, scale, qmax, llr, batch, hard, iters, app);
 }
 
 /* beta = 0: plain normalised min-sum (the committed golden vectors of round 1 were made with it) */

@@ -34,6 +34,7 @@ def lib():
         L.orc_encode.argtypes = [i32, i32, P, i32, P]
         L.orc_decode_nmsq.argtypes = [i32, i32, i32, i32, i32, f32, i32, P, i32, P, P, P]
         L.orc_decode_onmsq.argtypes = [i32, i32, i32, i32, i32, f32, f32, i32, P, i32, P, P, P]
+        L.orc_decode_onmsq_wide.argtypes = [i32, i32, i32, i32, i32, f32, f32, i32, i32, P, i32, P, P, P]
         L.orc_decode_bp_flood.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32]
         L.orc_decode_bp_flood_app.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32, P]
         L.orc_set_threads.argtypes = [i32]
@@ -91,6 +92,20 @@ def decode_nmsq(bg, Z, llr, max_iter, n_layers=0, early_term=False, alpha=0.75, 
                                 _p(hard), _p(iters), _p(app))
     assert rc == 0, rc
     return (hard, iters, app) if want_app else (hard, iters)
+
+
+def decode_nmsq_wide(bg, Z, llr, max_iter, n_layers=0, early_term=False, alpha=0.75, scale=8, beta=0.0, qmax=32767):
+    """decode_nmsq on a wide grid (values and messages saturate at +/-qmax instead of +/-127): not what the kernels compute;
+    used to measure what the 8-bit grid costs."""
+    rows, cols, kb = BG_DIMS[bg]
+    llr = np.ascontiguousarray(llr, np.float64).reshape(-1, cols * Z)
+    B = llr.shape[0]
+    hard = np.zeros((B, kb * Z), np.uint8)
+    iters = np.zeros(B, np.int32)
+    rc = lib().orc_decode_onmsq_wide(bg, Z, n_layers, max_iter, int(early_term), alpha, beta, scale, qmax, _p(llr), B,
+                                     _p(hard), _p(iters), None)
+    assert rc == 0, rc
+    return hard, iters
 
 
 def decode_bp_flood(bg, Z, llr, max_iter, n_layers=0, nthreads=0, want_app=False):

@@ -174,3 +174,161 @@ def test_db_gap_at_bler_1e2(pkg, orc, case):
     print(extra)
     assert x_gpu is not None and x_bp is not None, "grid does not bracket BLER 1e-2: %s %s" % (b_gpu, b_bp)
     assert x_gpu - x_bp <= BOUND_DB_1E2, extra
+
+
+# ---- round 4: the reference's own operating points ----------------------------------------------------
+def _record(name, extra):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        p = os.path.join(out, "bler_gap.json")
+        allr = json.load(open(p)) if os.path.exists(p) else {}
+        allr.setdefault(name, {"case": name}).update(extra)
+        json.dump(allr, open(p, "w"), indent=1)
+    except OSError:
+        pass
+    print(name, extra)
+
+
+BOUND_DB_50 = 0.15  # stated bound at the reference's default cap, 50 iterations against 50 sweeps (NRLDPCDecoder.m:41), BLER 1e-2
+# name, bg, Z, K', E, layers, grid of the GPU decoder, grid of the sum-product oracle, blocks
+CASES_50 = [
+    ("cfg2 headline BG1 Z=384 R=1/3 50it", 1, 384, 8448, 25272, 46, [-1.60, -1.55, -1.50, -1.45, -1.40], [-1.70, -1.65, -1.60, -1.55], 4096),
+    ("cfg3 BG2 Z=384 R=1/3 50it", 2, 384, 3840, 11472, 22, [-1.55, -1.45, -1.35, -1.25], [-1.65, -1.55, -1.45, -1.35], 4096),
+]
+
+
+@pytest.mark.parametrize("case", CASES_50, ids=[c[0] for c in CASES_50])
+def test_db_gap_at_the_reference_default_of_50_iterations(pkg, orc, case):
+    """Equal caps at the reference's DEFAULT `iterations = 50` (NRLDPCDecoder.m:41): 50 layered offset-min-sum iterations on
+    the GPU against 50 flooding sum-product sweeps, identical noise, crossing of BLER 1e-2 on 4096 blocks."""
+    name, bg, Z, Kp, E, nl, snrs, snrs_bp, nblk = case
+    rows, cols, kb = BG_DIMS[bg]
+    K = kb * Z
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    codec = pkg.Codec(bg, Z, max_iter=50, n_layers=nl, early_term=True, llr_dtype=np.float32)
+    info = rng.integers(0, 2, (nblk, K), dtype=np.uint8)
+    info[:, Kp:] = 0
+    cw = codec.encode(info)
+    noise = rng.standard_normal(cw.shape).astype(np.float32)
+
+    def llr_at(snr):
+        mu = 2 * 10 ** (snr / 10)
+        llr = ((1 - 2.0 * cw) * mu + np.sqrt(2 * mu) * noise).astype(np.float64)
+        llr[:, : 2 * Z] = 0
+        llr[:, 2 * Z + E + (K - Kp):] = 0
+        llr[:, Kp:K] = np.inf
+        return llr
+    b_gpu, it_gpu, b_bp, it_bp = [], [], [], []
+    for snr in snrs:
+        hg, ig = codec.decode(llr_at(snr).astype(np.float32), want_iters=True)
+        b_gpu.append(float((hg[:, :Kp] != info[:, :Kp]).any(1).mean())); it_gpu.append(float(ig.mean()))
+    for snr in snrs_bp:
+        hb, ib = orc.decode_bp_flood(bg, Z, llr_at(snr), 50, n_layers=nl, nthreads=_threads())
+        b_bp.append(float((hb[:, :Kp] != info[:, :Kp]).any(1).mean())); it_bp.append(float(ib.mean()))
+    codec.close()
+    x_gpu, x_bp = crossing(snrs, b_gpu, nblk, 1e-2), crossing(snrs_bp, b_bp, nblk, 1e-2)
+    rec = {"blocks": nblk, "iterations": 50, "EsN0_dB_gpu": snrs, "bler_gpu": b_gpu, "mean_iters_gpu": it_gpu,
+           "EsN0_dB_sum_product": snrs_bp, "bler_sum_product": b_bp, "mean_sweeps_sum_product": it_bp,
+           "EsN0_at_bler_0.01_gpu": x_gpu, "EsN0_at_bler_0.01_sum_product": x_bp,
+           "gap_dB_at_bler_0.01": None if x_gpu is None or x_bp is None else x_gpu - x_bp, "bound_dB": BOUND_DB_50}
+    _record(name, rec)
+    assert x_gpu is not None and x_bp is not None, "grids do not bracket BLER 1e-2: %s %s" % (b_gpu, b_bp)
+    assert x_gpu - x_bp <= BOUND_DB_50, rec
+
+
+def _reference_decoder_class(pkg, orc):
+    """The reference's receiver exactly as it is built: the System object's chain (NRLDPCDecoder.m:133-140) around
+    comm.LDPCDecoder(H, iterations, 'Parity check satisfied') (:120, :265) -- here the product's host-side mirror of that chain
+    with its stage 4 handed to the sum-product oracle on the full parity-check matrix (test infrastructure; no GPU involved)."""
+    class ReferenceDecoder(pkg.NRLDPCDecoder):
+        def LDPC_coding(self, d_tilde):  # NRLDPCDecoder.m:245-268
+            Z, K_ = self.Z_c, self.K
+            nb, C_ = d_tilde.shape[0], self.C
+            cw = np.concatenate([np.zeros((nb, C_, 2 * Z)), d_tilde], axis=2)  # :262
+            filler = np.isnan(cw[0, 0, :K_])
+            cw[np.isnan(cw)] = np.inf  # :264
+            hard, iters = orc.decode_bp_flood(self.BG, Z, cw.reshape(nb * C_, -1), self._setup_iterations, nthreads=_threads())  # :265
+            self.last_iterations = iters.reshape(nb, C_)
+            c_hat = hard.reshape(nb, C_, K_).astype(np.float64)
+            c_hat[:, :, filler] = np.nan  # :266
+            return c_hat
+    return ReferenceDecoder
+
+
+BOUND_DB_DEMO = 0.10
+# name, plot_BLER_vs_SNR.m arguments (A, R, BG, Modulation, rv_id_sequence, iterations), Es/N0 grid, transport blocks
+CASES_DEMO = [
+    # the script's own defaults (plot_BLER_vs_SNR.m:29-41): two code blocks of BG2 Z = 208, 8 iterations
+    ("demo A=3842 BG2 R=1/3 QPSK 8it rv[0]", 3842, 1 / 3, 2, "QPSK", (0,), 8, [-1.0, -0.5, 0.0, 0.5, 1.0], 512),
+    # the same point sent at R = 2/3 with up to four HARQ transmissions (:38's rv_id_sequence option, I_HARQ = 1 as :99)
+    ("demo A=3842 BG2 R=2/3 QPSK 8it rv[0 2 3 1]", 3842, 2 / 3, 2, "QPSK", (0, 2, 3, 1), 8, [-3.0, -2.5, -2.0, -1.5, -1.0], 512),
+    # one higher-order point: exact LLRs of the 64QAM demapper (NRDemodulator.m:80)
+    ("demo A=3842 BG2 R=1/2 64QAM 8it rv[0]", 3842, 1 / 2, 2, "64QAM", (0,), 8, [9.0, 9.5, 10.0, 10.5, 11.0], 512),
+]
+
+
+@pytest.mark.parametrize("case", CASES_DEMO, ids=[c[0] for c in CASES_DEMO])
+def test_db_gap_through_the_harness_at_the_reference_defaults(pkg, orc, case):
+    """plot_BLER_vs_SNR.m's own loop body (harness.simulate_point = :118-137: payload, NRLDPCEncoder, modulation, AWGN, exact
+    LLRs, NRLDPCDecoder with I_HARQ = 1 and the HARQ loop over rv_id_sequence) run twice on identical payloads and noise: with
+    the product's decoder object (GPU) and with the reference's receiver (same chain, sum-product core), both at the script's
+    `iterations = 8`.  Gap of the BLER 0.1 crossings."""
+    name, A, R, BG, mod, rvs, iters, snrs, nblk = case
+    import importlib
+    H = importlib.import_module(pkg.__name__ + ".harness")
+    Q_m = H.Q_M[mod]
+    G = int(round(A / R / Q_m) * Q_m)  # plot_BLER_vs_SNR.m:94
+    Ref = _reference_decoder_class(pkg, orc)
+    blers = {}
+    for tag, cls in (("gpu", pkg.NRLDPCDecoder), ("ref", Ref)):
+        hEnc = pkg.NRLDPCEncoder(A=A, BG=BG, G=G, Q_m=Q_m)
+        hDec = cls(A=A, BG=BG, G=G, Q_m=Q_m, I_HARQ=1, iterations=iters)
+        out = []
+        for snr in snrs:
+            rng = np.random.default_rng(zlib.crc32((name + str(snr)).encode()))  # the same payloads and noise for both receivers
+            ok = H.simulate_point(hEnc, hDec, Q_m, snr, rvs, nblk, rng)
+            out.append(float(1.0 - ok.mean()))
+        hEnc.release(); hDec.release()
+        blers[tag] = out
+    x_gpu, x_ref = crossing(snrs, blers["gpu"], nblk), crossing(snrs, blers["ref"], nblk)
+    rec = {"blocks": nblk, "iterations": iters, "A": A, "R": R, "BG": BG, "Modulation": mod, "rv_id_sequence": list(rvs), "G": G,
+           "EsN0_dB": snrs, "bler_gpu": blers["gpu"], "bler_reference_chain_sum_product": blers["ref"],
+           "EsN0_at_bler_0.1_gpu": x_gpu, "EsN0_at_bler_0.1_reference": x_ref,
+           "gap_dB": None if x_gpu is None or x_ref is None else x_gpu - x_ref, "bound_dB": BOUND_DB_DEMO}
+    _record(name, rec)
+    assert x_gpu is not None and x_ref is not None, "grid does not bracket BLER 0.1: %s" % blers
+    assert x_gpu - x_ref <= BOUND_DB_DEMO, rec
+
+
+def test_cost_of_the_8_bit_grid(pkg, orc):
+    """What the int8 grid costs: the SAME layered offset-min-sum rule on a wide grid -- channel values and
+    messages saturating at +/-32767 grid units instead of +/-127, i.e. no +/-15.9 LLR ingest clamp and 16-bit messages
+    (oracle/orc_decode_onmsq_wide; no kernel computes it) -- against the product on identical noise, headline code, 25
+    iterations, crossing of BLER 1e-2 on 4096 blocks.  Recorded and bounded: the 8-bit grid may cost at most 0.05 dB."""
+    name, bg, Z, Kp, E, nl, iters = "cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25
+    snrs, nblk = [-1.40, -1.35, -1.30, -1.25, -1.20], 4096
+    K = 22 * Z
+    rng = np.random.default_rng(zlib.crc32(b"8-bit grid"))
+    codec = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=True, llr_dtype=np.float32)
+    info = rng.integers(0, 2, (nblk, K), dtype=np.uint8)
+    cw = codec.encode(info)
+    noise = rng.standard_normal(cw.shape).astype(np.float32)
+    b8, bw = [], []
+    for snr in snrs:
+        mu = 2 * 10 ** (snr / 10)
+        llr = ((1 - 2.0 * cw) * mu + np.sqrt(2 * mu) * noise).astype(np.float32)
+        llr[:, : 2 * Z] = 0
+        llr[:, 2 * Z + E:] = 0
+        hg = codec.decode(llr)
+        hw, _ = orc.decode_nmsq_wide(bg, Z, llr.astype(np.float64), iters, n_layers=nl, early_term=True, **rule_kw(codec))
+        b8.append(float((hg != info).any(1).mean())); bw.append(float((hw != info).any(1).mean()))
+    codec.close()
+    x8, xw = crossing(snrs, b8, nblk, 1e-2), crossing(snrs, bw, nblk, 1e-2)
+    rec = {"grid_cost": {"blocks": nblk, "EsN0_dB": snrs, "bler_int8_grid_gpu": b8, "bler_wide_grid_oracle": bw,
+                         "EsN0_at_bler_0.01_int8": x8, "EsN0_at_bler_0.01_wide": xw,
+                         "cost_dB_of_the_8_bit_grid_at_bler_0.01": None if x8 is None or xw is None else x8 - xw,
+                         "note": "same rule (alpha, beta), same noise; wide = values and messages saturate at 32767 grid units"}}
+    _record(name, rec)
+    assert x8 is not None and xw is not None, (b8, bw)
+    assert x8 - xw <= 0.05, rec

@@ -91,6 +91,36 @@ def test_rate_pruned_layers(pkg, orc, bg, Z, nl, esn0):
     run_case(pkg, orc, rng, bg, Z, 5, esn0, 14, nl=nl, et=True, app=False)  # ... and its early-termination twin
 
 
+def _waterfall_esn0(bg, nl):
+    """Rough Es/N0 (dB) at which (bg, nl active rows) converges within a dozen iterations for about half the blocks."""
+    pts = {1: [(4, 8.0), (5, 6.2), (8, 4.6), (13, 3.0), (17, 2.0), (24, 1.0), (30, 0.2), (46, -0.8)],
+           2: [(4, 7.0), (7, 4.5), (9, 2.6), (12, 1.3), (17, 0.0), (22, -0.7), (32, -1.8), (42, -2.5)]}[bg]
+    return float(np.interp(nl, [p[0] for p in pts], [p[1] for p in pts]))
+
+
+# every kernel family a hard-output call with pruned rows can land on: split form (block geometry; 384 and 288 with dual rows),
+# one-thread-per-row pipelined form (144, 192, 320, 352; BG2 384), packed geometry (8 ... 80), run-time-Z kernel (the rest)
+RT_GRID_Z = (8, 20, 32, 56, 64, 80, 96, 128, 144, 192, 208, 256, 288, 320, 352, 384)
+RT_GRID_NL = (4, 5, 8, 13, 17, 24, 30)
+
+
+@pytest.mark.parametrize("bg", [1, 2])
+@pytest.mark.parametrize("Z", RT_GRID_Z)
+def test_run_time_layer_count_grid(pkg, orc, bg, Z):
+    """Pruned layer counts that have no build of their own run the pipelined / split / packed kernels with the count as a
+    run-time prefix of the all-rows tables (NL_RT, nrldpc_device.h): after 1, 2 and 3 iterations at an SNR where nothing
+    converges (one stale copy of a ring word shows), then 25 fixed iterations and the parity-check stop in the waterfall."""
+    rng = np.random.default_rng(7000 + 100 * bg + Z)
+    rows = BG_DIMS[bg][0]
+    B = 3 + (300 // Z if Z < 64 else 0)
+    for nl in RT_GRID_NL + (rows - 1,):
+        w = _waterfall_esn0(bg, nl)
+        for iters in (1, 2, 3):
+            run_case(pkg, orc, rng, bg, Z, B, w - 2.5, iters, nl=nl, et=False, app=False, dt=np.float16 if (nl + iters) % 2 else np.float32)
+        run_case(pkg, orc, rng, bg, Z, B, w, 25, nl=nl, et=False, app=False)
+        run_case(pkg, orc, rng, bg, Z, B + 2, w + 0.2, 14, nl=nl, et=True, app=False)
+
+
 @pytest.mark.parametrize("bg", [1, 2])
 def test_z384_kernel_variants(pkg, orc, bg):
     """The compile-time Z=384 kernel has three builds (plain fixed-iteration, full-H with early

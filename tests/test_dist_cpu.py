@@ -95,3 +95,6 @@ def test_bench_rank_protocol_runs_under_gloo():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["ms_per_step"] >= 2.0  # max over ranks: rank 1 sleeps 2 ms
+    # the strong-scaled leg (BASELINE configs[4]) cuts ONE job over the ranks: contiguous halves of the 65536 codewords
+    leg = rec["cfg5_strong"]
+    assert leg["scaling"] == "strong" and [g["codewords"] for g in leg["per_gpu"]] == [32768, 32768]

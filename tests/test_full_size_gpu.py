@@ -257,13 +257,19 @@ def test_bench_two_ranks_sharing_one_gpu():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--batch", "1024", "--backend", "gloo", "--share-gpu"]
+           "--batch", "1024", "--backend", "gloo", "--share-gpu", "--cfg5-total", "4096", "--cfg5-steps", "2"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["value"] > 1.0 and rec["bler"] < 0.05 and "cpu_baseline" not in rec
+    assert len(rec["roofline"]["per_gpu"]) == 2 and all(g["kernel_ms"] > 0 for g in rec["roofline"]["per_gpu"])
+    # the strong-scaled leg of BASELINE configs[4]: the job's 4096 codewords cut over the two ranks, every one decoded
+    leg = rec["cfg5_strong"]
+    assert leg["scaling"] == "strong" and leg["n_gpus"] == 2 and leg["value"] > 1.0
+    assert [g["codewords"] for g in leg["per_gpu"]] == [2048, 2048]
+    assert all(g["bler"] < 0.05 and 1.0 <= g["mean_iterations"] < 10.0 and 0.0 < g["hbm_frac"] < 1.0 for g in leg["per_gpu"])
 
 
 def test_cfg5_full_batch_65536_through_eight_shards(pkg, orc):
