@@ -53,8 +53,9 @@ typedef struct nrldpc_codec* nrldpc_handle;
 /* ABI revision of this header.  Revision 3 put `struct_size` in front of nrldpc_cfg and nrldpc_dims (revision 2 had
  * grown both at the tail -- beta; alpha, beta -- with nothing a caller built against revision 1 could be told apart by).
  * nrldpc_abi_version() returns the revision the loaded library was built with (the library is loaded by path and has
- * no SONAME; a binding checks this number at load time, as ldpc-3gpp-matlab_amd/_capi.py does). */
-#define NRLDPC_ABI_VERSION 3
+ * no SONAME; a binding checks this number at load time, as ldpc-3gpp-matlab_amd/_capi.py does).
+ * Revision 4 adds nrldpc_decode_packed (no struct changed). */
+#define NRLDPC_ABI_VERSION 4
 
 typedef struct nrldpc_cfg {
     uint32_t struct_size; /* = sizeof(nrldpc_cfg); nrldpc_create refuses any other value (NRLDPC_ERR_ARG)      */
@@ -96,6 +97,11 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
                   float* app_out);
 int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t* d_hard,
                       int32_t* d_iters_out, float* d_app_out, void* stream);
+/* nrldpc_decode with BIT-PACKED hard decisions: hard_packed: [batch][ceil(K/8)] bytes, bit k of a codeword in byte k/8 at bit
+ * k%8 (least significant first; the unused bits of a codeword's last byte are 0).  The bits are packed on the device, so an
+ * eighth of the bytes crosses PCIe and the copy into the caller's array: the form a MEX gateway uses (matlab/nrldpc_mex.cpp
+ * unpacks into the K x C logical array the reference's comm.LDPCDecoder returns, NRLDPCDecoder.m:265). */
+int nrldpc_decode_packed(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard_packed, int32_t* iters_out);
 
 /* The quantisation nrldpc_decode applies to large host batches while it copies them into its pinned staging
  * buffers (so that 1 byte per LLR crosses PCIe instead of 4): dst[i] = NaN ? 0 : rint(clamp(float(src[i]) * llr_scale,

@@ -25,7 +25,7 @@ class NRLDPCError(RuntimeError):
     identifier = "ldpc_3gpp_matlab:Error"
 
 
-ABI_VERSION = 3  # NRLDPC_ABI_VERSION of include/nrldpc.h
+ABI_VERSION = 4  # NRLDPC_ABI_VERSION of include/nrldpc.h
 
 
 class Cfg(C.Structure):
@@ -72,7 +72,7 @@ EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev",  "nrldpc_crc_check_
            "nrldpc_decode_multi_dev", "nrldpc_quantise_llr", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version", "nrldpc_build_id", "nrldpc_kernel_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
-           "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version"]
+           "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version", "nrldpc_decode_packed"]
 
 _lib = None
 
@@ -125,6 +125,7 @@ def load():
     L.nrldpc_destroy.restype = None
     L.nrldpc_get_dims.argtypes = [vp, C.POINTER(Dims)]
     L.nrldpc_decode.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.nrldpc_decode_packed.argtypes = [vp, vp, i32, vp, vp]
     L.nrldpc_decode_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.nrldpc_quantise_llr.argtypes = [vp, vp, C.c_int64, i32, i32]
     L.nrldpc_decode_multi_dev.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), vp]
@@ -225,6 +226,18 @@ class Codec:
         if want_app:
             out += (app,)
         return out[0] if len(out) == 1 else out
+
+    def decode_packed(self, llr, want_iters=False):
+        """nrldpc_decode_packed: hard decisions as [B][ceil(K/8)] bytes, bit k of a codeword in byte k // 8 at bit k % 8
+        (np.unpackbits(out, axis=1, bitorder="little")[:, :K] gives decode()'s array)."""
+        llr = np.ascontiguousarray(llr, self.llr_dtype)
+        if llr.size % self.N_cw:
+            raise NRLDPCError("llr should hold a whole number of codewords of length %d" % self.N_cw)
+        B = llr.size // self.N_cw
+        packed = np.empty((B, (self.K + 7) // 8), np.uint8)
+        iters = np.empty(B, np.int32) if want_iters else None
+        check(self._lib.nrldpc_decode_packed(self._h, _ptr(llr), B, _ptr(packed), _ptr(iters)))
+        return (packed, iters) if want_iters else packed
 
     def encode(self, info):
         info = np.ascontiguousarray(info, np.uint8)

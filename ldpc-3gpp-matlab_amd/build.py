@@ -33,7 +33,7 @@ Z64P_PAIRS = [(1, z) for z in Z64P_BG1] + [(2, z) for z in Z64P_BG2]
 Z64P_NL = [(2, 20, 12)]
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7), (2, 208, 21)]
-HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h"]
+HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h", "nrldpc_hostpath.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DNRLDPC_Z64_AB"] if AB else [])
 
 
@@ -80,6 +80,38 @@ def kernel_id():
     return h.hexdigest()[:16]
 
 
+_INC = None
+
+
+def _includes(path, seen):
+    """Files `path` includes with #include "...", transitively (looked up next to it, in csrc/ and in include/)."""
+    import re
+    try:
+        text = open(path, encoding="utf-8", errors="replace").read()
+    except OSError:
+        return
+    for name in re.findall(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', text, re.M):
+        for d in (os.path.dirname(path), CSRC, INCLUDE):
+            q = os.path.join(d, name)
+            if os.path.exists(q):
+                q = os.path.abspath(q)
+                if q not in seen:
+                    seen.add(q)
+                    _includes(q, seen)
+                break
+
+
+def _unit_id(src, flags, defs):
+    h = hashlib.sha256()
+    seen = set()
+    _includes(src, seen)
+    for f in [src] + sorted(seen):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    h.update(("\0".join([*flags, *defs])).encode())
+    return h.hexdigest()[:24]
+
+
 def _stale():
     """The library is missing, or was built from other sources than the ones in the tree now."""
     if not os.path.exists(LIB):
@@ -110,22 +142,12 @@ def build_lib(force=False, verbose=False, jobs=None):
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64P_NL]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64_NL]
-    # An object is reused only when it was compiled from exactly these inputs: contents of its source and of every
-    # header, the flags and the -D list (sidecar <obj>.id) -- never by modification time, which a snapshot copy, rsync -t
-    # or tar may set to anything.  nrldpc_capi carries the build id of the whole tree, so it is keyed by that as well.
-    hh = hashlib.sha256()
-    for d in sorted(_deps()):
-        if not d.endswith((".hip", ".cpp")):
-            with open(d, "rb") as f:
-                hh.update(os.path.basename(d).encode() + b"\0" + f.read())
-    headers_id = hh.hexdigest()
-
+    # An object is reused only when it was compiled from exactly these inputs: contents of its source and of every header
+    # it includes (transitively, by scanning #include "..." lines: a change to the C ABI does not recompile 130 decoder
+    # units), the flags and the -D list (sidecar <obj>.id) -- never by modification time, which a snapshot copy, rsync -t or
+    # tar may set to anything.  nrldpc_capi carries the build id of the whole tree in its -D list, so it is keyed by that too.
     def unit_id(src, flags, defs):
-        h = hashlib.sha256()
-        with open(src, "rb") as f:
-            h.update(f.read())
-        h.update(("\0".join([headers_id, *flags, *defs])).encode())
-        return h.hexdigest()[:24]
+        return _unit_id(src, flags, defs)
 
     def compile_one(u):
         src, obj, defs = u

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "nrldpc.h"
+#include "nrldpc_hostpath.h"
 #include "nrldpc_kernels.h"
 #include "nrldpc_host_quant.h"
 #include "nrldpc_sched.h"
@@ -327,7 +328,7 @@ struct nrldpc_codec {
     // host-entry staging
     DevBuf<char> s_llr;
     DevBuf<int8_t> s_q; // int8 chunks of the pipelined host path, one region per slot
-    DevBuf<uint8_t> s_hard, s_bits;
+    DevBuf<uint8_t> s_hard, s_bits, s_pk; // s_pk: bit-packed hard decisions (nrldpc_decode_packed)
     DevBuf<int32_t> s_iters;
     DevBuf<float> s_app;
     std::vector<float> h_narrow;
@@ -581,7 +582,7 @@ void nrldpc_destroy(nrldpc_handle h) {
     DeviceScope scope(h->cfg.device_id);
     h->d_rot.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
-    h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_iters.release(); h->s_app.release();
+    h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_pk.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
     for (int i = 0; i < 3; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
@@ -752,7 +753,13 @@ int nrldpc_quantise_llr(int8_t* dst, const void* src, int64_t n, int32_t llr_dty
     return nrldpc_quantise_i8(dst, src, (size_t)n, kind, (float)llr_scale) ? 1 : 0;
 }
 
-int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out) {
+} // extern "C"
+
+namespace {
+// nrldpc_decode / nrldpc_decode_packed: `packed` = the hard decisions leave as one BIT per bit ([batch][ceil(K/8)] bytes, least
+// significant bit first) instead of one byte per bit -- packed on the device, so that an eighth of the bytes crosses PCIe and
+// goes through the copy into the caller's array
+int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out, bool packed) {
     NRLDPC_API_BEGIN
     if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
@@ -761,11 +768,13 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     DEVICE_SCOPE(h);
     const nrldpc::Schedule& s = h->sched;
     const size_t ncw = (size_t)s.g.ncols * s.Z, K = (size_t)s.g.kb * s.Z;
+    const size_t KO = packed ? (K + 7) / 8 : K; // bytes of one codeword's hard decisions in the caller's array
     const size_t cap = (h->cfg.max_batch > batch) ? (size_t)h->cfg.max_batch : (size_t)batch;
     const bool f64 = h->cfg.llr_dtype == NRLDPC_LLR_F64;
     const size_t eb = llr_elem_bytes(h->cfg.llr_dtype); // on the device (MATLAB doubles are narrowed to f32 on the host)
     HIP_TRY(h->s_llr.reserve(cap * ncw * eb));
     HIP_TRY(h->s_hard.reserve(cap * K));
+    if (packed) HIP_TRY(h->s_pk.reserve(cap * KO));
     if (iters_out) HIP_TRY(h->s_iters.reserve(cap));
     if (app_out) HIP_TRY(h->s_app.reserve(cap * ncw));
 
@@ -825,7 +834,8 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
             const double t0 = now();
             HIP_TRY(hipEventSynchronize(h->xdone[sl]));
             const double t1 = now();
-            h->pool->move(hard + (size_t)c0 * K, h->pin_out[sl].p, (size_t)n * K, false);
+            if (packed) memcpy(hard + (size_t)c0 * KO, h->pin_out[sl].p, (size_t)n * KO); // an eighth of the bytes: not worth a fan-out
+            else h->pool->move(hard + (size_t)c0 * K, h->pin_out[sl].p, (size_t)n * K, false);
             t_wait += t1 - t0; t_out += now() - t1;
             if (iters_out) memcpy(iters_out + c0, h->pin_it[sl].p, (size_t)n * 4);
             return NRLDPC_OK;
@@ -857,7 +867,12 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
             int rc = decode_launch(h, d_in, n, h->s_hard.p + (size_t)c0 * K, iters_out ? h->s_iters.p + c0 : nullptr, nullptr, h->xs[st], kind);
             if (rc) return rc;
             t_quant += tq1 - tq0; t_enq -= tq1;
-            HIP_TRY(hipMemcpyAsync(h->pin_out[sl].p, h->s_hard.p + (size_t)c0 * K, (size_t)n * K, hipMemcpyDeviceToHost, h->xs[st]));
+            if (packed) {
+                HIP_TRY(nrldpc::launch_pack_bits(h->s_hard.p + (size_t)c0 * K, h->s_pk.p + (size_t)c0 * KO, n, (int)K, h->xs[st]));
+                HIP_TRY(hipMemcpyAsync(h->pin_out[sl].p, h->s_pk.p + (size_t)c0 * KO, (size_t)n * KO, hipMemcpyDeviceToHost, h->xs[st]));
+            } else {
+                HIP_TRY(hipMemcpyAsync(h->pin_out[sl].p, h->s_hard.p + (size_t)c0 * K, (size_t)n * K, hipMemcpyDeviceToHost, h->xs[st]));
+            }
             if (iters_out) HIP_TRY(hipMemcpyAsync(h->pin_it[sl].p, h->s_iters.p + c0, (size_t)n * 4, hipMemcpyDeviceToHost, h->xs[st]));
             HIP_TRY(hipEventRecord(h->xdone[sl], h->xs[st]));
             t_enq += now();
@@ -882,12 +897,28 @@ int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard
     int rc = decode_launch(h, h->s_llr.p, batch, h->s_hard.p, iters_out ? h->s_iters.p : nullptr,
                            app_out ? h->s_app.p : nullptr, nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(hard, h->s_hard.p, (size_t)batch * K, hipMemcpyDeviceToHost, nullptr));
+    if (packed) {
+        HIP_TRY(nrldpc::launch_pack_bits(h->s_hard.p, h->s_pk.p, batch, (int)K, nullptr));
+        HIP_TRY(hipMemcpyAsync(hard, h->s_pk.p, (size_t)batch * KO, hipMemcpyDeviceToHost, nullptr));
+    } else {
+        HIP_TRY(hipMemcpyAsync(hard, h->s_hard.p, (size_t)batch * K, hipMemcpyDeviceToHost, nullptr));
+    }
     if (iters_out) HIP_TRY(hipMemcpyAsync(iters_out, h->s_iters.p, (size_t)batch * 4, hipMemcpyDeviceToHost, nullptr));
     if (app_out) HIP_TRY(hipMemcpyAsync(app_out, h->s_app.p, (size_t)batch * ncw * 4, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     return NRLDPC_OK;
     NRLDPC_API_END
+}
+} // namespace
+
+extern "C" {
+
+int nrldpc_decode(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out) {
+    return decode_host(h, llr, batch, hard, iters_out, app_out, false);
+}
+
+int nrldpc_decode_packed(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard_packed, int32_t* iters_out) {
+    return decode_host(h, llr, batch, hard_packed, iters_out, nullptr, true);
 }
 
 } // extern "C"

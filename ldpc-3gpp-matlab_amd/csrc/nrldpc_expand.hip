@@ -12,6 +12,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include "nrldpc_hostpath.h"
 #include "nrldpc_kernels.h"
 
 namespace nrldpc {
@@ -51,6 +52,39 @@ hipError_t launch_expand_i8(const int8_t* d_q, void* d_out_f16, size_t n, float 
     const size_t want = ((vec ? n >> 4 : n) + 255) / 256;
     const int grid = (int)(want < 1 ? 1 : want > 8192 ? 8192 : want);
     hipLaunchKernelGGL(nrldpc_expand_i8_kernel, dim3(grid), dim3(256), 0, stream, d_q, static_cast<__half*>(d_out_f16), n, inv_scale, vec);
+    return hipGetLastError();
+}
+
+// ---- hard decisions, one byte per bit -> one bit per bit (nrldpc_decode_packed: 8x fewer bytes over PCIe and through the
+// caller's copy).  One thread per output byte; rows whose length and address allow it read their eight input bytes as one
+// 64-bit word and gather the bits with one multiply (bytes are 0 / 1: byte j lands on bit 56 + j, no carries meet).
+__global__ __launch_bounds__(256) void nrldpc_pack_bits_kernel(const uint8_t* __restrict__ hard, uint8_t* __restrict__ packed, int rows,
+                                                               int K, int KB8, int wide) {
+    const size_t total = (size_t)rows * KB8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / KB8;
+        const int b = (int)(i - r * KB8);
+        const uint8_t* src = hard + r * (size_t)K + 8 * (size_t)b;
+        uint32_t v;
+        if (wide) {
+            const uint64_t x = *reinterpret_cast<const uint64_t*>(src) & 0x0101010101010101ull;
+            v = (uint32_t)((x * 0x0102040810204080ull) >> 56);
+        } else {
+            v = 0;
+            const int n = K - 8 * b < 8 ? K - 8 * b : 8;
+            for (int j = 0; j < n; ++j) v |= (uint32_t)(src[j] & 1u) << j;
+        }
+        packed[i] = (uint8_t)v;
+    }
+}
+
+hipError_t launch_pack_bits(const uint8_t* d_hard, uint8_t* d_packed, int rows, int K, hipStream_t stream) {
+    if (rows <= 0 || K <= 0) return hipSuccess;
+    const int KB8 = (K + 7) / 8;
+    const int wide = (K % 8 == 0) && (reinterpret_cast<uintptr_t>(d_hard) & 7) == 0;
+    const size_t want = ((size_t)rows * KB8 + 255) / 256;
+    const int grid = (int)(want > 16384 ? 16384 : want);
+    hipLaunchKernelGGL(nrldpc_pack_bits_kernel, dim3(grid), dim3(256), 0, stream, d_hard, d_packed, rows, K, KB8, wide);
     return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@
 #include "nrldpc_host_quant.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -138,5 +139,7 @@ bool nrldpc_quantise_i8_path(int8_t* dst, const void* src, size_t n, int src_kin
 }
 
 bool nrldpc_quantise_i8(int8_t* dst, const void* src, size_t n, int src_kind, float scale) {
-    return nrldpc_quantise_i8_path(dst, src, n, src_kind, scale, -1);
+    // NRLDPC_HOST_QUANT_PATH=0/1/2 names the code path (tests compare them; A/B of the host path); read per call, a call is a chunk
+    const char* e = getenv("NRLDPC_HOST_QUANT_PATH");
+    return nrldpc_quantise_i8_path(dst, src, n, src_kind, scale, e ? atoi(e) : -1);
 }

@@ -102,12 +102,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         check(nrldpc_get_dims(h, &d));
         need((int)mxGetM(prhs[2]) == d.N_cw, "cw_tilde should have N+2*Z_c rows.");
         const int C = (int)mxGetN(prhs[2]);
-        std::vector<uint8_t> hard((size_t)d.K * (size_t)(C > 0 ? C : 1));
+        // bit-packed over PCIe (nrldpc_decode_packed, ABI revision 4): K/8 bytes per column come back instead of K
+        const size_t KB8 = ((size_t)d.K + 7) / 8;
+        std::vector<uint8_t> packed(KB8 * (size_t)(C > 0 ? C : 1));
         mxArray* it = mxCreateNumericMatrix(C, 1, mxINT32_CLASS, mxREAL);
-        check(nrldpc_decode(h, mxGetPr(prhs[2]), C, hard.data(), (int32_t*)mxGetData(it), nullptr));
+        check(nrldpc_decode_packed(h, mxGetPr(prhs[2]), C, packed.data(), (int32_t*)mxGetData(it)));
         plhs[0] = mxCreateDoubleMatrix(d.K, C, mxREAL);                // K x C double {0,1}, what double(step(...)) gives, :265
         double* o = mxGetPr(plhs[0]);
-        for (size_t i = 0; i < (size_t)d.K * C; ++i) o[i] = (double)hard[i];
+        for (int c = 0; c < C; ++c)
+            for (int k = 0; k < d.K; ++k) o[(size_t)c * d.K + k] = (double)((packed[(size_t)c * KB8 + (k >> 3)] >> (k & 7)) & 1);
         if (nlhs > 1) plhs[1] = it; else mxDestroyArray(it);
     } else if (!strcmp(cmd, "encode")) {
         need(nrhs == 3 && mxIsDouble(prhs[2]) && !mxIsComplex(prhs[2]), "encode needs a handle and a real double matrix.");

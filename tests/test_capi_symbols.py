@@ -60,6 +60,13 @@ def test_host_quantiser_is_the_kernels_ingest(pkg):
                 if neg:
                     x[k[5]] = -np.inf
                 q, flag = pkg._capi.quantise_llr(x, scale)
+                for path in ("0", "1", "2"):  # plain C++, AVX2 + F16C, AVX-512 (a path the CPU lacks falls to the next one down)
+                    os.environ["NRLDPC_HOST_QUANT_PATH"] = path
+                    try:
+                        qp, fp = pkg._capi.quantise_llr(x, scale)
+                    finally:
+                        del os.environ["NRLDPC_HOST_QUANT_PATH"]
+                    assert (qp == q).all() and fp == flag, (dt, scale, n, path)
                 x32 = x.astype(np.float32)
                 with np.errstate(invalid="ignore", over="ignore"):
                     y = x32 * np.float32(scale)
@@ -129,13 +136,13 @@ def test_mex_gateway_compiles_against_the_stub_mex_api():
 
 
 def test_abi_revision_and_struct_size_guard(pkg):
-    """ABI revision 3: nrldpc_cfg / nrldpc_dims carry their size; a caller built against another revision is refused
+    """ABI revision 3 (kept by revision 4, which only adds nrldpc_decode_packed): nrldpc_cfg / nrldpc_dims carry their size; a caller built against another revision is refused
     instead of having memory past its struct read or written."""
     C = pkg._capi
     lib = pkg.load()
-    assert lib.nrldpc_abi_version() == C.ABI_VERSION == 3
+    assert lib.nrldpc_abi_version() == C.ABI_VERSION == 4
     hdr = open(os.path.join(ROOT, "include", "nrldpc.h")).read()
-    assert "#define NRLDPC_ABI_VERSION 3" in hdr
+    assert "#define NRLDPC_ABI_VERSION 4" in hdr
     cfg = C.Cfg(1, 384, 0, 10, 1, 0.0, 0, 0, 0, 0)
     assert cfg.struct_size == ctypes.sizeof(C.Cfg)
     cfg.struct_size = ctypes.sizeof(C.Cfg) - 4  # the r1 layout (no beta)

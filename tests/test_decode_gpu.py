@@ -244,6 +244,27 @@ def test_golden_fixture_on_gpu(pkg):
         assert (np.packbits(cw, axis=1) == g[name + "/cw_packed"]).all(), name
 
 
+@pytest.mark.parametrize("bg,Z,B", [(1, 384, 700), (2, 7, 33), (1, 3, 5), (2, 96, 9000), (1, 64, 1)])
+def test_bit_packed_hard_output(pkg, orc, bg, Z, B):
+    """nrldpc_decode_packed (ABI revision 4): the same decisions as nrldpc_decode, bit k of a codeword in byte k // 8 at bit
+    k % 8, unused bits of the last byte zero -- lifting sizes whose K is not a multiple of 8 (K = 66, 70), a batch large
+    enough for the pipelined host path (> 8 MB of LLRs), and one codeword."""
+    rng = np.random.default_rng(800 + Z)
+    kb = BG_DIMS[bg][2]
+    K = kb * Z
+    info = rng.integers(0, 2, (min(B, 64), K), dtype=np.uint8)
+    cw = np.tile(orc.encode(bg, Z, info), (-(-B // info.shape[0]), 1))[:B]
+    llr = awgn_llr(rng, cw, 1.0, np.float16, Z)
+    for dt in (np.float16, np.float64):
+        c = pkg.Codec(bg, Z, max_iter=8, early_term=True, llr_dtype=dt)
+        hard, it = c.decode(llr.astype(dt), want_iters=True)
+        packed, itp = c.decode_packed(llr.astype(dt), want_iters=True)
+        c.close()
+        assert packed.shape == (B, (K + 7) // 8) and (itp == it).all()
+        bits = np.unpackbits(packed, axis=1, bitorder="little")
+        assert (bits[:, :K] == hard).all() and not bits[:, K:].any()
+
+
 def test_empty_and_argument_errors(pkg):
     c = pkg.Codec(1, 8, max_iter=3)
     assert c.decode(np.zeros((0, c.N_cw), np.float32)).shape == (0, c.K)
