@@ -46,7 +46,7 @@ ALG_BYTES_PER_CW = ITERS * 4 * S_BYTES * NNZ * Z + N_CW * S_BYTES + K // 8  # 12
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2  # 256 CUs x 4 SIMDs, one wave64 VALU op per 2 cycles (MI355X_MICROARCH.md)
 # rocprofv3 summaries of this very command (tools/profile_gpu.sh + tools/summarise_profile.py); newest round first
-PROFILE_TAGS = ("r03", "r02", "r01")
+PROFILE_TAGS = ("r04", "r03", "r02", "r01")
 
 
 def _profile(kernel_id):
@@ -477,7 +477,10 @@ def main():
         alg_gbs = batch * ALG_BYTES_PER_CW / (kernel_ms * 1e-3) / 1e9
         roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave64 VALU instructions/s",
                 "frac": None, "traffic": traffic, "kernel": pmc.get("_kernel"), "kernel_ms": kernel_ms,
-                "kernel_ms_median": float(np.median(kms)), "kernel_ms_min": float(np.min(kms))}
+                "kernel_ms_median": float(np.median(kms)), "kernel_ms_min": float(np.min(kms)),
+                # the same kernel's average under rocprofv3 --kernel-trace (first launch left out), from the committed profile
+                # of this build: tracing adds a few per cent; kernel_ms above is what every fraction of this line divides by
+                "kernel_ms_rocprofv3_avg": (pmc.get("_kernel_trace", {}).get("avg_ns_without_first_launch") or 0.0) * 1e-6 * (batch / float(BATCH)) or None}
         if c("SQ_INSTS_VALU"):
             insts = c("SQ_INSTS_VALU")
             rate = insts / (kernel_ms * 1e-3)

@@ -54,7 +54,8 @@ typedef struct nrldpc_codec* nrldpc_handle;
  * grown both at the tail -- beta; alpha, beta -- with nothing a caller built against revision 1 could be told apart by).
  * nrldpc_abi_version() returns the revision the loaded library was built with (the library is loaded by path and has
  * no SONAME; a binding checks this number at load time, as ldpc-3gpp-matlab_amd/_capi.py does).
- * Revision 4 adds nrldpc_decode_packed (no struct changed). */
+ * Revision 4 adds nrldpc_decode_packed and the CRC-aided stop (early_term = 2; crc_poly, crc_len, crc_bits at the tail of
+ * nrldpc_cfg). */
 #define NRLDPC_ABI_VERSION 4
 
 typedef struct nrldpc_cfg {
@@ -63,7 +64,9 @@ typedef struct nrldpc_cfg {
     int32_t Z;          /* lifting size Z_c, one of the 51 of Table 5.3.2-1 (NRLDPC.m:409-411)    */
     int32_t n_layers;   /* base rows to decode, 4..46 (BG1) / 4..42 (BG2); 0 = all (reference: all) */
     int32_t max_iter;   /* 'MaximumIterationCount' (NRLDPCDecoder.m:41,120); 1..2000              */
-    int32_t early_term; /* 1 = stop a codeword when all active parity checks hold (reference: 1)  */
+    int32_t early_term; /* 0 = always max_iter iterations; 1 = stop a codeword when all active parity checks hold (the
+                           reference: 'Parity check satisfied', NRLDPCDecoder.m:120); 2 = that, or when the CRC of the
+                           code block holds on the hard decisions (crc_* below) -- see "CRC-aided stop"              */
     float alpha;        /* min-sum normalisation factor, 0 < alpha <= 1; 0 = choose alpha AND beta by code rate
                            (nrldpc_default_rule: the rule whose BLER sits closest to the reference's sum-product) */
     int32_t llr_scale;  /* fixed-point units per unit LLR: power of two 1..32; 0 = default 8 */
@@ -73,6 +76,17 @@ typedef struct nrldpc_cfg {
     float beta;         /* min-sum offset in LLR units (>= 0), read only when alpha != 0: message magnitude =
                            max(alpha*min - beta, 0) on the fixed-point grid; 0 = plain normalised min-sum; rounded to
                            the nearest 1/(2*llr_scale) LLR (nrldpc_get_dims reports the value in use)               */
+    /* CRC-aided stop, read only when early_term == 2 (else leave 0).  The reference checks a code block's CRC AFTER decoding
+     * (CRC24B per code block when C > 1, else the transport block's CRC24A / CRC16: NRLDPCDecoder.m:298-301, 336;
+     * get_3gpp_crc_polynomial.m:3-14); here the same check also ends the iterations of a codeword whose information bits are
+     * already right while a parity bit is not: after an iteration a codeword is done when its active parity checks hold, OR
+     * when the first crc_bits hard decisions (payload followed by its CRC, K' of NRLDPC.m) leave remainder 0 under crc_poly and
+     * are not all zero (an all-zero block has remainder 0 whatever was sent; with rv_id 2 / 3 the punctured systematic bits
+     * start at a-posteriori 0, i.e. hard decision 0).  Hard decisions and iteration counts are those of the oracle's
+     * orc_decode_onmsq_crc.  Measured against the parity-check stop: profiles/r04_crc_stop.json. */
+    uint32_t crc_poly;  /* generator polynomial with its x^crc_len term, e.g. CRC24B 0x1800063, CRC24A 0x1864CFB, CRC16 0x11021 */
+    int32_t crc_len;    /* L: 24 or 16 for TS 38.212 (6..24 accepted)                                   */
+    int32_t crc_bits;   /* K' = payload + CRC bits of the code block, crc_len < crc_bits <= K            */
 } nrldpc_cfg;
 
 /* Dimensions implied by (bg, Z): ncols*Z LLRs in, K = kb*Z hard bits out. */

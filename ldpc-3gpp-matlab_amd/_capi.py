@@ -32,7 +32,8 @@ class Cfg(C.Structure):
     """nrldpc_cfg; struct_size is filled in by the constructor (positional arguments start at bg)."""
     _fields_ = [("struct_size", C.c_uint32), ("bg", C.c_int32), ("Z", C.c_int32), ("n_layers", C.c_int32), ("max_iter", C.c_int32),
                 ("early_term", C.c_int32), ("alpha", C.c_float), ("llr_scale", C.c_int32),
-                ("llr_dtype", C.c_int32), ("device_id", C.c_int32), ("max_batch", C.c_int32), ("beta", C.c_float)]
+                ("llr_dtype", C.c_int32), ("device_id", C.c_int32), ("max_batch", C.c_int32), ("beta", C.c_float),
+                ("crc_poly", C.c_uint32), ("crc_len", C.c_int32), ("crc_bits", C.c_int32)]
 
 
 def _cfg_init(self, *args, **kw):
@@ -182,15 +183,17 @@ class Codec:
     comm.LDPCDecoder / comm.LDPCEncoder in the reference (NRLDPCDecoder.m:120, NRLDPCEncoder.m:49)."""
 
     def __init__(self, bg, Z, max_iter=50, n_layers=0, early_term=True, alpha=0.0, llr_scale=0,
-                 llr_dtype=np.float32, device_id=0, max_batch=0, beta=0.0):
+                 llr_dtype=np.float32, device_id=0, max_batch=0, beta=0.0, crc=None):
         """alpha = 0: the library picks the check-node rule (alpha, beta) by rate (nrldpc_default_rule);
-        otherwise message magnitude = max(alpha*min - beta, 0), beta in LLR units."""
+        otherwise message magnitude = max(alpha*min - beta, 0), beta in LLR units.
+        crc = (poly with its x^L term, L, K'): the CRC-aided stop (nrldpc_cfg.early_term = 2) on the first K' information bits."""
         L = load()
         self._lib = L
         self._h = C.c_void_p()
         self.llr_dtype = np.dtype(llr_dtype)
-        cfg = Cfg(int(bg), int(Z), int(n_layers), int(max_iter), int(bool(early_term)), float(alpha),
-                  int(llr_scale), _NP2DT[self.llr_dtype], int(device_id), int(max_batch), float(beta))
+        cfg = Cfg(int(bg), int(Z), int(n_layers), int(max_iter), 2 if crc else int(bool(early_term)), float(alpha),
+                  int(llr_scale), _NP2DT[self.llr_dtype], int(device_id), int(max_batch), float(beta),
+                  *((int(crc[0]), int(crc[1]), int(crc[2])) if crc else (0, 0, 0)))
         check(L.nrldpc_create(C.byref(cfg), C.byref(self._h)))
         d = Dims(C.sizeof(Dims))
         check(L.nrldpc_get_dims(self._h, C.byref(d)))

@@ -26,8 +26,8 @@ Z64_BG1 = (60, 64, 104, 112, 120, 128, 144, 176, 192, 208, 224, 240, 256, 288, 3
 Z64_BG2 = (52, 60, 64, 88, 96, 104, 112, 120, 128, 144, 192, 208, 224, 240, 256, 288, 320, 352, 384)
 Z64_PAIRS = [(1, z) for z in Z64_BG1] + [(2, z) for z in Z64_BG2]
 # = NRLDPC_Z64P_LIST: the packed geometry (a workgroup's row lanes carry several whole codewords)
-Z64P_BG1 = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52, 56, 72, 80, 88, 96, 144, 160, 176, 288, 320, 352)
-Z64P_BG2 = Z64P_BG1
+Z64P_BG1 = (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52, 56, 72, 80, 88, 96, 176, 352)
+Z64P_BG2 = Z64P_BG1[:-4]
 Z64P_PAIRS = [(1, z) for z in Z64P_BG1] + [(2, z) for z in Z64P_BG2]
 # = NRLDPC_Z64P_NL_LIST: (BG, Z, active layers) with packed builds of their own
 Z64P_NL = [(2, 20, 12)]

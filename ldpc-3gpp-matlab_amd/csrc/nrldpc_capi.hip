@@ -320,6 +320,7 @@ struct nrldpc_codec {
     int scale = 8;
     // device tables
     DevBuf<int32_t> d_rot;
+    DevBuf<uint32_t> d_crc; // x^(crc_bits-1-i) mod g, i < crc_bits: the CRC-aided stop's table (early_term = 2)
     DevBuf<uint16_t> d_row_ptr, d_shift;
     DevBuf<uint8_t> d_col;
     // encoder solve order
@@ -422,6 +423,7 @@ nrldpc::DecArgs make_dec_args(const nrldpc_codec* h, const void* d_llr, int batc
     a.rot = h->d_rot.p;
     a.batch = batch; a.Z = s.Z; a.n_layers = s.n_layers; a.max_iter = h->cfg.max_iter; a.ncw = s.ncw; a.sbw = s.sbw;
     a.early_term = h->cfg.early_term ? 1 : 0;
+    if (h->cfg.early_term == 2) { a.crc_tab = h->d_crc.p; a.crc_bits = h->cfg.crc_bits; }
     a.need_ext = (a.early_term || d_app) ? 1 : 0;
     a.llr_kind = llr_kind >= 0 ? llr_kind : (h->cfg.llr_dtype == NRLDPC_LLR_F16) ? NRLDPC_K_F16 : NRLDPC_K_F32;
     a.alpha = h->alpha; a.scale = (float)h->scale; a.inv_scale = 1.0f / (float)h->scale;
@@ -523,6 +525,14 @@ int nrldpc_create(const nrldpc_cfg* cfg_in, nrldpc_handle* out) {
     }
     if (!(alpha > 0.0f && alpha <= 1.0f)) return fail(NRLDPC_ERR_UNSUPPORTED, "alpha must be in (0,1]");
     if (!(beta >= 0.0f && beta <= 4.0f)) return fail(NRLDPC_ERR_UNSUPPORTED, "beta must be in [0,4] LLR units");
+    if (cfg->early_term < 0 || cfg->early_term > 2) return fail(NRLDPC_ERR_UNSUPPORTED, "early_term must be 0, 1 or 2");
+    if (cfg->early_term == 2) { // CRC-aided stop: generator with its x^L term, L = 6 ... 24, over the first crc_bits information bits
+        const int kb = cfg->bg == 1 ? 22 : 10;
+        if (cfg->crc_len < 6 || cfg->crc_len > 24 || (cfg->crc_poly >> cfg->crc_len) != 1u || !(cfg->crc_poly & 1u))
+            return fail(NRLDPC_ERR_UNSUPPORTED, "early_term = 2 needs crc_poly = the generator with its x^crc_len and x^0 terms, crc_len in 6..24");
+        if (cfg->crc_bits <= cfg->crc_len || cfg->crc_bits > kb * cfg->Z)
+            return fail(NRLDPC_ERR_UNSUPPORTED, "early_term = 2 needs crc_len < crc_bits <= K (payload and CRC of one code block)");
+    }
     int scale = cfg->llr_scale == 0 ? 8 : cfg->llr_scale;
     if (scale != 1 && scale != 2 && scale != 4 && scale != 8 && scale != 16 && scale != 32)
         return fail(NRLDPC_ERR_UNSUPPORTED, "llr_scale must be a power of two in 1..32");
@@ -569,6 +579,22 @@ int nrldpc_create(const nrldpc_cfg* cfg_in, nrldpc_handle* out) {
     CREATE_TRY(hipMemcpy(h->d_row_ptr.p, s.g.row_ptr, (s.g.nrows + 1) * 2, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(h->d_col.p, s.g.col, s.g.nnz, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(h->d_shift.p, sh16.data(), s.g.nnz * 2, hipMemcpyHostToDevice));
+    if (cfg->early_term == 2) {
+        // tab[i] = x^(n-1-i) mod g: bit i of the block (first bit = highest power, as comm.CRCDetector reads it,
+        // NRLDPCDecoder.m:113-115) contributes this to the remainder; built from the last bit backwards by x -> x*x mod g
+        const int n = cfg->crc_bits, L = cfg->crc_len;
+        std::vector<uint32_t> tab((size_t)n);
+        uint32_t r = 1u; // x^0
+        const uint32_t top = 1u << L;
+        for (int i = n - 1; i >= 0; --i) {
+            tab[(size_t)i] = r;
+            r <<= 1;
+            if (r & top) r ^= cfg->crc_poly;
+        }
+        CREATE_TRY(h->d_crc.reserve((size_t)n));
+        CREATE_TRY(hipMemcpy(h->d_crc.p, tab.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        h->sched.lds_bytes += 4 * (size_t)nrldpc::CRC_SLOTS * h->sched.ncw + 16; // the run-time-Z kernel's slots, behind its flags
+    }
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
 #undef CREATE_TRY
@@ -580,7 +606,7 @@ int nrldpc_create(const nrldpc_cfg* cfg_in, nrldpc_handle* out) {
 void nrldpc_destroy(nrldpc_handle h) {
     if (!h) return;
     DeviceScope scope(h->cfg.device_id);
-    h->d_rot.release();
+    h->d_rot.release(); h->d_crc.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
     h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_pk.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
@@ -818,7 +844,16 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
         if (i8) HIP_TRY(h->s_q.reserve(q_slot * NS));
         for (int i = 0; i < 2; ++i)
             if (!h->xs[i]) HIP_TRY(hipStreamCreateWithFlags(&h->xs[i], hipStreamNonBlocking));
-        const int nchunks = (batch + chunk - 1) / chunk;
+        // Chunk k = codewords [starts[k], starts[k+1]).  The first chunk's copy + H2D is the one stretch of a call in which the
+        // device has nothing to do, so a call of several rounds opens with two half chunks (one workgroup per CU each).
+        static const bool env_ramp = !(getenv("NRLDPC_HOST_RAMP") && atoi(getenv("NRLDPC_HOST_RAMP")) == 0); // A/B
+        std::vector<int> starts(1, 0);
+        for (int pos = 0, k = 0; pos < batch; ++k) {
+            const int want = (env_ramp && k < 2 && chunk >= 512 && batch >= 3 * chunk) ? chunk / 2 : chunk;
+            pos += std::min(want, batch - pos);
+            starts.push_back(pos);
+        }
+        const int nchunks = (int)starts.size() - 1;
         h->pool->follow(llr, (size_t)batch * ncw * host_eb);
         // an early error return must not leave copies or kernels of this call in flight on the two streams
         struct Quiesce {
@@ -830,7 +865,7 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         int drained = 0; // chunks 0 .. drained-1 are back in the caller's arrays
         auto drain = [&](int k) -> int { // results of chunk k: pinned slot -> caller arrays
-            const int sl = k % NS, c0 = k * chunk, n = std::min(chunk, batch - c0);
+            const int sl = k % NS, c0 = starts[k], n = starts[k + 1] - c0;
             const double t0 = now();
             HIP_TRY(hipEventSynchronize(h->xdone[sl]));
             const double t1 = now();
@@ -841,7 +876,7 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             return NRLDPC_OK;
         };
         for (int k = 0; k < nchunks; ++k) {
-            const int sl = k % NS, st = k & 1, c0 = k * chunk, n = std::min(chunk, batch - c0);
+            const int sl = k % NS, st = k & 1, c0 = starts[k], n = starts[k + 1] - c0;
             // the slot's previous chunk has to be out (that also frees pin_in[sl]); chunks that happen to be finished
             // are taken out now rather than in one lump at the end
             while (drained <= k - NS || (drained < k && hipEventQuery(h->xdone[drained % NS]) == hipSuccess)) {

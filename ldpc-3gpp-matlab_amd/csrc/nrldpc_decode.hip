@@ -208,7 +208,18 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
         });
         if (a.early_term) {
             if (tid <= a.ncw) flags[tid] = 0; // flags[ncw] = "some codeword of this workgroup still fails"
+            // CRC-aided stop (early_term = 2): per codeword CRC_SLOTS words behind the flags (16-byte aligned)
+            int* crc_slots = flags + ((a.ncw + 1 + 3) & ~3) + cwl * CRC_SLOTS;
+            if (a.crc_bits && tid < a.ncw * CRC_SLOTS) flags[((a.ncw + 1 + 3) & ~3) + tid] = 0;
             __syncthreads();
+            if (!done && a.crc_bits) { // every thread folds the information bits at its own ring position z of each column
+                CrcFold f;
+                static_for<G::KB>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    f.bit(*reinterpret_cast<const float*>(lds + zb + 4 * c), a.crc_tab, c * Z + z, a.crc_bits);
+                });
+                f.publish(crc_slots);
+            }
             if (!done) {
                 // One violated check settles a codeword's answer.  A lane that has found one publishes it at
                 // once; at every vote point (each core row, then every 4 rows) a lane whose codeword is already
@@ -229,6 +240,14 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
                 if (bad) { flags[cwl] = 1; flags[a.ncw] = 1; }
             }
             __syncthreads();
+            if (a.crc_bits) {
+                // a codeword whose CRC holds is done although a parity check fails; the workgroup leaves when none is left
+                if (!done && flags[cwl] != 0 && crc_holds(crc_slots)) { done = true; my_iters = it; }
+                if (tid == 0) flags[a.ncw] = 0;
+                __syncthreads();
+                if (!done && flags[cwl] != 0) flags[a.ncw] = 1;
+                __syncthreads();
+            }
             if (!done && flags[cwl] == 0) { done = true; my_iters = it; }
             if (flags[a.ncw] == 0) break;
         }
@@ -342,7 +361,9 @@ bool has_z64p_kernel(int bg, int Z, bool early_term) {
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream) {
     const bool force_generic = force_generic_env();
     static const bool no_packed = getenv("NRLDPC_NO_PACKED") != nullptr;
-    if (!force_generic && !no_packed && !a.app) { // pruned layer counts with packed builds of their own
+    // (the CRC-aided stop, early_term = 2, lives in the block-geometry and run-time-Z kernels: packed sizes take those then)
+    const bool crc = a.crc_bits != 0;
+    if (!force_generic && !no_packed && !a.app && !crc) { // pruned layer counts with packed builds of their own
 #define NRLDPC_Z64P_NL_CASE(b, z, nl) if (bg == b && a.Z == z && a.n_layers == nl) return launch_decode_z64p_##b##_##z##_nl##nl(a, stream);
         NRLDPC_Z64P_NL_LIST(NRLDPC_Z64P_NL_CASE)
 #undef NRLDPC_Z64P_NL_CASE
@@ -350,13 +371,13 @@ hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes
     // the packed builds: hard output; every row active, or any other layer count as a run-time prefix (NL_RT; NRLDPC_NO_RT=1
     // sends those to the kernels that served them before -- A/B)
     static const bool no_rt = getenv("NRLDPC_NO_RT") != nullptr;
-    if (!a.app && (a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) || !no_rt) && has_z64p_kernel(bg, a.Z, a.early_term != 0)) {
+    if (!a.app && !crc && (a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) || !no_rt) && has_z64p_kernel(bg, a.Z, a.early_term != 0)) {
 #define NRLDPC_Z64P_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64p_##b##_##z(a, stream);
         NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE
     }
     static const bool no_packed_general = getenv("NRLDPC_NO_PACKED_GENERAL") != nullptr; // A/B against the run-time-Z kernel
-    if (bg == 2 && !force_generic && !no_packed && !no_packed_general && !has_z64_kernel(bg, a.Z)) {
+    if (bg == 2 && !crc && !force_generic && !no_packed && !no_packed_general && !has_z64_kernel(bg, a.Z)) {
         // the packed geometry's general kernel: any layer count, soft output -- BG2 (nrldpc_decode_z64p.h: z64pg_serves); sizes
         // with a block-geometry build keep that one's
 #define NRLDPC_Z64P_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64pg_##b##_##z(a, stream);

@@ -98,11 +98,14 @@ constexpr int z64p_rw(int BG, int Z) {
     return NRLDPC_Z64P_RW;
 #endif
     (void)BG;
-    // Large lifting sizes that do not split into full waves in the block geometry (9, 11, 5 or 3 times a power of two: blocks of
-    // 40-48 rows leave 25-37 % of the lanes idle): 6-wave halves -- the 12-wave workgroup shape of Z = 384's split kernel -- carry
-    // 352 rows (4 x 88, 2 x 176, 1 x 352) or 384 (4 x 96), 5-wave halves 288 (2 x 144, 1 x 288) or 320 (2 x 160, 1 x 320)
-    if (Z == 88 || Z == 96 || Z == 176 || Z == 352) return 6;
-    if (Z == 144 || Z == 160 || Z == 288 || Z == 320) return 5;
+    // Large lifting sizes of BG1 that do not split into full waves in the block geometry (11 or 3 times a power of two: blocks of
+    // 44-48 rows leave 25-31 % of the lanes idle): 6-wave halves -- the 12-wave workgroup shape of Z = 384's split kernel -- carry
+    // 352 rows (4 x 88, 2 x 176, 1 x 352) or 384 (4 x 96).  Measured against the kernels these sizes ran before, one session
+    // (profiles/r04_packed_large.json, edge updates per ns): Z = 88 2507 -> 2830, 96 2730 -> 3247, 176 2905 -> 3035, 352 2412 ->
+    // 3001.  Not adopted after the same measurement: 5-wave halves (Z = 144, 160, 288, 320: 10-wave workgroups, 1522-1994 against
+    // 2708-3155) and every BG2 size (88 ... 352: 2278-2780 against 2847-3266 -- BG2's one-thread-per-row form already runs 6
+    // waves per SIMD with 80 registers, and the packed image doubles its rings).
+    if (BG == 1 && (Z == 88 || Z == 96 || Z == 176 || Z == 352)) return 6;
     int best = 1, fill = -1;
     for (int rw = 1; rw <= 4; rw *= 2) {
         const int f = (64 * rw / Z) * Z * 1000 / (64 * rw);
@@ -265,7 +268,9 @@ template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROW
         return (n < 0 || shift(n) % BLK > shift(e) % BLK) ? TW_ALWAYS : TW_IF_LAST;
     }
     // + one trailing guard (the last column's block-0 twin write overshoots into it) + termination flags
-    static constexpr size_t lds_bytes() { return (size_t)NCWG * CWS + GUARD + 16 * ((NCWG + 1 + 3) / 4); }
+    // ... + the CRC-aided stop's partial remainders (CrcFold, nrldpc_device.h), CRC_SLOTS words per codeword
+    static constexpr size_t FLAG_BYTES = 16 * ((NCWG + 1 + 3) / 4);
+    static constexpr size_t lds_bytes() { return (size_t)NCWG * CWS + GUARD + FLAG_BYTES + 4 * (size_t)CRC_SLOTS * NCWG; }
 };
 
 // binary decision tree on the (wave-uniform) wave index: at most ceil(log2(HI-LO)) scalar branches
@@ -985,7 +990,18 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
     // violated-check vote of one codeword's waves -> flags; returns after the closing barrier
     auto parity_pass = [&](int it) {
         if (tid <= G::NCWG) flags[tid] = 0;
+        int* crc_slots = flags + G::FLAG_BYTES / 4 + cwl * CRC_SLOTS; // CRC-aided stop (early_term = 2)
+        if (a.crc_bits && tid < G::NCWG * CRC_SLOTS) flags[G::FLAG_BYTES / 4 + tid] = 0;
         __syncthreads();
+        if (!done && a.crc_bits) { // the information bits at this thread's own ring position z of every column (primary copy:
+            CrcFold f;             // a column's last writer of an iteration leaves both copies fresh)
+            const char* home = lds + cwbase + G::GUARD + 4 * z;
+            static_for<G::KB>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                f.bit(*reinterpret_cast<const float*>(home + c * G::CS), a.crc_tab, c * ZC + z, a.crc_bits);
+            });
+            f.publish(crc_slots);
+        }
         if (!done) {
             // A violated check anywhere settles the answer, so a wave stops reading as soon as one of its
             // 64 rows has failed (voted after each core row, then every 4 rows; this also bounds the loads in flight):
@@ -1017,8 +1033,18 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         // readfirstlane: the flags are wave-uniform by construction, and `done` has to be *provably* so --
         // as a divergent predicate it wraps the whole iteration in exec-mask control flow with phi copies
         // of all 80 state registers (measured: 168 VGPRs + 234 spills instead of 129 and none)
-        const int mine = __builtin_amdgcn_readfirstlane(flags[cwl]);
-        const int any = __builtin_amdgcn_readfirstlane(flags[G::NCWG]);
+        int mine = __builtin_amdgcn_readfirstlane(flags[cwl]);
+        int any = __builtin_amdgcn_readfirstlane(flags[G::NCWG]);
+        if (a.crc_bits && any != 0) {
+            // a codeword whose CRC holds is done although one of its parity checks fails; then "is anybody left" is asked again
+            if (!done && mine != 0 && __builtin_amdgcn_readfirstlane((int)crc_holds(crc_slots))) mine = 0;
+            __syncthreads();
+            if (tid == 0) flags[G::NCWG] = 0;
+            __syncthreads();
+            if (!done && mine != 0) flags[G::NCWG] = 1;
+            __syncthreads();
+            any = __builtin_amdgcn_readfirstlane(flags[G::NCWG]);
+        }
         if (!done && mine == 0) { done = true; my_iters = it; }
         return any == 0; // every codeword of the workgroup has converged
     };

@@ -48,7 +48,8 @@ template <int BG, int ZC, int NL> struct Z64S : Z64<BG, ZC, 1, NL> {
     static constexpr int THREADS = 2 * B::TPC;
     static constexpr bool usable() { return THREADS <= 1024 && NG >= 2; }
     // rings + trailing guard + flags [+ the extension-column channel LLRs, one int8 per extension row and row-thread]
-    static constexpr size_t XOFF = (size_t)B::CWS + B::GUARD + 16;
+    // (16 bytes of flags, then the CRC-aided stop's CRC_SLOTS words, nrldpc_device.h: CrcFold)
+    static constexpr size_t XOFF = (size_t)B::CWS + B::GUARD + 16 + 4 * (size_t)CRC_SLOTS;
     static constexpr size_t XBYTES = (size_t)(B::NLT - 4) * ZC;
     // Workgroups a CU holds: 24 wave slots at the 80-VGPR budget, 160 KB of LDS.  The extension LLRs move from 6 registers
     // per thread into LDS exactly where that does not cost a workgroup (Z = 384, 288, 256, 240 ... : the wave slots bind;
@@ -364,7 +365,21 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
             if constexpr (ETP) {
                 // parity check of this half's rows (see parity_pass of the one-thread-per-row kernel)
                 if (u == 0) flags[0] = 0;
+                int* crc_slots = flags + 4; // CRC-aided stop (early_term = 2)
+                if (a.crc_bits && u < CRC_SLOTS) crc_slots[u] = 0;
                 __syncthreads();
+                if (a.crc_bits) { // this half's columns (alternate ones), the bit at this thread's own ring position z (primary copy)
+                    CrcFold f;
+                    int tz = threadIdx.x; // derived again from the thread id: z is not kept live across the iteration for this
+                    asm volatile("" : "+v"(tz));
+                    const int zz = ((tz >> 6) % G::NWV) * G::BLK + (tz & 63);
+                    const char* home = lds + G::GUARD + 4 * zz;
+                    static_for<(G::KB + 1) / 2>([&](auto kc) {
+                        constexpr int c = 2 * decltype(kc)::value + H;
+                        if constexpr (c < G::KB) f.bit(*reinterpret_cast<const float*>(home + c * G::CS), a.crc_tab, c * ZC + zz, a.crc_bits);
+                    });
+                    f.publish(crc_slots);
+                }
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform
                 constexpr auto PO = O::parity_order(); // cheapest rows first
@@ -382,6 +397,10 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
                 if (bad) flags[0] = 1;
                 __syncthreads();
                 if (__builtin_amdgcn_readfirstlane(flags[0]) == 0) { my_iters = it; break; }
+                if (a.crc_bits) { // the CRC of the information bits holds although a parity check does not: done as well
+                    // (the slots are reset in the next parity pass, a whole iteration of barriers away from this read)
+                    if (__builtin_amdgcn_readfirstlane((int)crc_holds(crc_slots)) != 0) { my_iters = it; break; }
+                }
             }
         }
         if constexpr (!ETP) __syncthreads(); // the last group's writes

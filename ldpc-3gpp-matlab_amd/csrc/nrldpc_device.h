@@ -274,6 +274,35 @@ template <int BG, int NL, int H, int XS, int V> struct DecStateS<BG, NL, H, XS, 
     template <int XI> __device__ __forceinline__ void set_ext(float q) { f32_to_byte<XI & 3>(xq[XI >> 2], q); }
 };
 
+// ---- CRC-aided stop (nrldpc_cfg.early_term = 2; SURVEY 8f row N2, NRLDPCDecoder.m:298-301,336) ----------------------------------
+// A codeword also stops iterating when the CRC over its first crc_bits hard decisions holds although some parity check does
+// not (the information bits are usually right an iteration before the last parity bit is).  The CRC is linear: the remainder
+// of the block is the XOR of x^(n-1-i) mod g over its set bits i, a table the host builds once (DecArgs::crc_tab).  Every thread
+// folds the bits it can read from its own ring positions, the lanes of a wave XOR their partial remainders into 16 LDS words
+// (ds_xor_b32: lanes that own no row simply take no part), and after the barrier the parity pass needs anyway every thread
+// reads the 16 words back.  An all-zero block has remainder 0 whatever it means -- punctured systematic bits whose a-posteriori
+// value is still 0 decide "0" -- so a block passes only if at least one of its bits is set (slot 16).
+struct CrcFold {
+    uint32_t acc = 0, any = 0;
+    __device__ __forceinline__ void bit(float app, const uint32_t* __restrict__ tab, int pos, int nbits) {
+        if (pos < nbits) {
+            const uint32_t neg = 0u - (fbits(app) >> 31); // all ones when the hard decision is 1
+            acc ^= tab[pos] & neg;
+            any |= neg;
+        }
+    }
+    __device__ __forceinline__ void publish(int* slots) const {
+        if (acc) atomicXor(&slots[threadIdx.x & 15], (int)acc);
+        if (any) slots[16] = 1;
+    }
+};
+__device__ __forceinline__ bool crc_holds(const int* slots) {
+    const int4 a = *reinterpret_cast<const int4*>(slots), b = *reinterpret_cast<const int4*>(slots + 4),
+               c = *reinterpret_cast<const int4*>(slots + 8), d = *reinterpret_cast<const int4*>(slots + 12);
+    const int r = a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    return r == 0 && slots[16] != 0;
+}
+
 // The same for the software-pipelined builds, with nbeta23 = 2^23 - beta held in a VGPR: v_fma + v_max + v_sub
 // (2.5 + 4 + 2.3 issue cycles; a separate v_rndne would cost 4 more).  The caller's search started from
 // (127.49 + beta)/alpha, so no upper clamp is needed.

@@ -22,14 +22,20 @@
 
 namespace nrldpc {
 
+constexpr int CRC_SLOTS = 20; // LDS ints per codeword of the CRC-aided stop: 16 partial remainders, 1 "a bit is set" flag, 3 of padding
+
 struct DecArgs {
     const void* llr;     // [batch][ncols*Z] f32 or f16
     uint8_t* hard;       // [batch][kb*Z]
     int32_t* iters;      // [batch] or null
     float* app;          // [batch][ncols*Z] or null
     const int32_t* rot;  // per table edge: ring rotation P_e * sbw in bytes (nrldpc_sched.h)
+    // CRC-aided stop (nrldpc_cfg.early_term = 2): crc_tab[i] = x^(crc_bits-1-i) mod g for the first crc_bits information bits of a
+    // codeword (payload + CRC of one code block, NRLDPCDecoder.m:298-301,336); null / 0 = parity-check stop only
+    const uint32_t* crc_tab;
     int32_t batch, Z, n_layers, max_iter, ncw, sbw;
     int32_t early_term, need_ext, llr_kind;
+    int32_t crc_bits;
     float alpha, scale, inv_scale;
     float beta;          // offset in grid units: message magnitude = clamp(rint(alpha*m - beta), 0, 127)
 };
@@ -51,8 +57,8 @@ NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
 // packed-geometry compile-time-Z builds (nrldpc_decode_z64p.h, nrldpc_decode_z64p_inst.hip): several codewords per wave, the
 // lifting sizes <= 32; every row active and hard output only -- other calls stay with the run-time-Z kernel
 #define NRLDPC_Z64P_LIST(X) \
-    X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 8) X(1, 9) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(1, 15) X(1, 16) X(1, 18) X(1, 20) X(1, 22) X(1, 24) X(1, 26) X(1, 28) X(1, 30) X(1, 32) X(1, 36) X(1, 40) X(1, 44) X(1, 48) X(1, 52) X(1, 56) X(1, 72) X(1, 80) X(1, 88) X(1, 96) X(1, 144) X(1, 160) X(1, 176) X(1, 288) X(1, 320) X(1, 352) \
-    X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 7) X(2, 8) X(2, 9) X(2, 10) X(2, 11) X(2, 12) X(2, 13) X(2, 14) X(2, 15) X(2, 16) X(2, 18) X(2, 20) X(2, 22) X(2, 24) X(2, 26) X(2, 28) X(2, 30) X(2, 32) X(2, 36) X(2, 40) X(2, 44) X(2, 48) X(2, 52) X(2, 56) X(2, 72) X(2, 80) X(2, 88) X(2, 96) X(2, 144) X(2, 160) X(2, 176) X(2, 288) X(2, 320) X(2, 352)
+    X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 8) X(1, 9) X(1, 10) X(1, 11) X(1, 12) X(1, 13) X(1, 14) X(1, 15) X(1, 16) X(1, 18) X(1, 20) X(1, 22) X(1, 24) X(1, 26) X(1, 28) X(1, 30) X(1, 32) X(1, 36) X(1, 40) X(1, 44) X(1, 48) X(1, 52) X(1, 56) X(1, 72) X(1, 80) X(1, 88) X(1, 96) X(1, 176) X(1, 352) \
+    X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 7) X(2, 8) X(2, 9) X(2, 10) X(2, 11) X(2, 12) X(2, 13) X(2, 14) X(2, 15) X(2, 16) X(2, 18) X(2, 20) X(2, 22) X(2, 24) X(2, 26) X(2, 28) X(2, 30) X(2, 32) X(2, 36) X(2, 40) X(2, 44) X(2, 48) X(2, 52) X(2, 56) X(2, 72) X(2, 80)
 // ... of which these serve fixed iteration counts only: with the parity-check stop the block-geometry split build of the
 // same size is faster (BG2 Z = 52: 0.44 against 0.54 ms; at 25 fixed iterations the packed build wins by 9 %)
 #define NRLDPC_Z64P_NOT_ET(X) X(2, 52)

@@ -31,13 +31,14 @@ class NRLDPCDecoder(NRLDPC):
     _NONTUNABLE = NRLDPC._NONTUNABLE + ("I_HARQ",)
     _TUNABLE = NRLDPC._TUNABLE + ("iterations",)
 
-    def __init__(self, device_id=0, alpha=None, llr_scale=0, prune_layers=True, beta=0.0, **kw):
+    def __init__(self, device_id=0, alpha=None, llr_scale=0, prune_layers=True, beta=0.0, crc_stop=False, **kw):
         self._I_HARQ = 0        # NRLDPCDecoder.m:34
         self._iterations = 50   # NRLDPCDecoder.m:41
         super().__init__(**kw)
         self._device_id, self._alpha, self._llr_scale = device_id, alpha, llr_scale
         self._beta = beta  # read only with an explicit alpha (nrldpc_cfg.beta)
         self._prune = prune_layers
+        self._crc_stop = bool(crc_stop)  # also stop a code block when its CRC holds (nrldpc_cfg.early_term = 2); the reference: False
         self._codec = None
         self._codec_layers = None
         self._nb = 1
@@ -66,7 +67,8 @@ class NRLDPCDecoder(NRLDPC):
             self._codec.close()
         self._codec = Codec(self.BG, self.Z_c, max_iter=self._setup_iterations, n_layers=n_layers,
                             early_term=True, alpha=self._alpha or 0.0, beta=self._beta, llr_scale=self._llr_scale,
-                            llr_dtype=np.float32, device_id=self._device_id)
+                            llr_dtype=np.float32, device_id=self._device_id,
+                            crc=self.code_block_check() if self._crc_stop else None)
         self._codec_layers = n_layers
 
     def _setup(self):  # NRLDPCDecoder.m:107-130

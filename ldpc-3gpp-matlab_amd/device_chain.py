@@ -17,11 +17,12 @@ class DeviceDecodeChain:
     code_block_CRC_passed flags (`cb_pass`); reset() clears them (:343-356).  CBGTI of `params` is honoured (:304)."""
 
     def __init__(self, params: NRLDPC, iterations=50, I_HARQ=0, alpha=None, llr_scale=0, prune_layers=True,
-                 llr_dtype=np.float16, device_id=0, beta=0.0):
+                 llr_dtype=np.float16, device_id=0, beta=0.0, crc_stop=False):
         import torch
         self.torch = torch
         params.validate()
         self.p = params
+        self.crc_stop = bool(crc_stop)  # nrldpc_cfg.early_term = 2: a code block also stops when its CRC holds
         self.iterations, self.I_HARQ = int(iterations), int(I_HARQ)
         self.alpha, self.beta, self.llr_scale, self.prune = alpha, beta, llr_scale, prune_layers
         self.llr_dtype = np.dtype(llr_dtype)
@@ -45,7 +46,8 @@ class DeviceDecodeChain:
         if self._codec is None or self._codec_layers != n_layers:
             self.close()
             self._codec = Codec(self.p.BG, self.p.Z_c, max_iter=self.iterations, n_layers=n_layers, early_term=True,
-                                alpha=self.alpha or 0.0, beta=self.beta, llr_scale=self.llr_scale, llr_dtype=self.llr_dtype, device_id=self.device_id)
+                                alpha=self.alpha or 0.0, beta=self.beta, llr_scale=self.llr_scale, llr_dtype=self.llr_dtype, device_id=self.device_id,
+                                crc=self.p.code_block_check() if self.crc_stop else None)
             self._codec_layers = n_layers
         return self._codec
 

@@ -155,6 +155,14 @@ class NRLDPC:
     def code_block_L(self):
         return get_3gpp_crc_polynomial(self.code_block_CRC)[1]
 
+    def code_block_check(self):
+        """(generator polynomial with its x^L term, L, K') of the CRC that closes every code block: the code-block CRC24B
+        when the transport block is segmented, else the transport block's own CRC (NRLDPCDecoder.m:298-301, 336) -- the
+        `crc` argument of Codec for the CRC-aided stop (nrldpc_cfg.early_term = 2)."""
+        if self.C > 1:
+            return (self.code_block_CRC_polynomial, self.code_block_L, int(self.K_prime))
+        return (self.transport_block_CRC_polynomial, self.transport_block_L, int(self.K_prime))
+
     @property
     def C(self):  # NRLDPC.m:334-344
         if self.B <= self.K_cb:

@@ -230,8 +230,23 @@ static int32_t scale_mag(float alpha, float beta, int32_t m, int qmax) {
     return (int32_t)f;
 }
 
+/* CRC-aided stop (nrldpc_cfg.early_term = 2; the reference checks these CRCs after decoding, NRLDPCDecoder.m:298-301,336):
+ * remainder of the first `bits` hard decisions (first bit = highest power) under the generator `poly` (with its x^L term),
+ * bit-serial as get_3gpp_crc_polynomial.m's polynomials are used; the block passes when the remainder is 0 and a bit is set. */
+typedef struct { uint32_t poly; int L, bits; } orc_crc_stop;
+static int crc_block_ok(const int32_t* APP, const orc_crc_stop* c) {
+    uint32_t r = 0, any = 0;
+    for (int i = 0; i < c->bits; ++i) {
+        const uint32_t b = APP[i] < 0;
+        any |= b;
+        r = (r << 1) | b;
+        if (r >> c->L) r ^= c->poly;
+    }
+    return r == 0 && any;
+}
+
 static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_term, float alpha, float beta, int qmax,
-                    const int32_t* q, uint8_t* hard, int32_t* app_q, int16_t* rmsg, int32_t* APP) {
+                    const int32_t* q, uint8_t* hard, int32_t* app_q, int16_t* rmsg, int32_t* APP, const orc_crc_stop* crc) {
     const int Z = g->Z;
     const int N = g->ncols * Z;
     memcpy(APP, q, sizeof(int32_t) * (size_t)N);
@@ -273,6 +288,7 @@ static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_te
                     bad |= p;
                 }
             if (!bad) break;
+            if (crc && crc_block_ok(APP, crc)) break;
         }
     }
     if (it > max_iter) it = max_iter;
@@ -284,7 +300,7 @@ static int nmsq_one(const orc_graph* g, int n_layers, int max_iter, int early_te
 /* llr: [batch][ncols*Z] double.  hard: [batch][K] bytes.  iters: [batch] or NULL.
  * app: [batch][ncols*Z] float (APP/scale) or NULL. */
 static int decode_onmsq_q(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, float beta, int scale, int qmax,
-                          const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
+                          const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app, const orc_crc_stop* crc) {
     orc_graph g;
     int rc = graph_init(&g, bg, Z);
     if (rc) return rc;
@@ -300,7 +316,7 @@ static int decode_onmsq_q(int bg, int Z, int n_layers, int max_iter, int early_t
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < batch; ++b) {
             for (size_t v = 0; v < N; ++v) q[v] = ingest(llr[b * N + v], scale, (int)(v / Z) < g.kb + 4, qmax);
-            int it = nmsq_one(&g, n_layers, max_iter, early_term, alpha, beta, qmax, q, hard + b * K, aq, rm, APP);
+            int it = nmsq_one(&g, n_layers, max_iter, early_term, alpha, beta, qmax, q, hard + b * K, aq, rm, APP, crc);
             if (iters) iters[b] = it;
             if (app)
                 for (size_t v = 0; v < N; ++v) app[b * N + v] = (float)aq[v] / (float)scale;
@@ -312,7 +328,15 @@ static int decode_onmsq_q(int bg, int Z, int n_layers, int max_iter, int early_t
 
 int orc_decode_onmsq(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, float beta, int scale,
                      const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
-    return decode_onmsq_q(bg, Z, n_layers, max_iter, early_term, alpha, beta, scale, ORC_QMAX, llr, batch, hard, iters, app);
+    return decode_onmsq_q(bg, Z, n_layers, max_iter, early_term, alpha, beta, scale, ORC_QMAX, llr, batch, hard, iters, app, NULL);
+}
+
+/* orc_decode_onmsq with early termination by parity check OR by the code block's CRC (nrldpc_cfg.early_term = 2) */
+int orc_decode_onmsq_crc(int bg, int Z, int n_layers, int max_iter, float alpha, float beta, int scale, uint32_t crc_poly, int crc_len,
+                         int crc_bits, const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
+    if (crc_len < 6 || crc_len > 24 || (crc_poly >> crc_len) != 1u || crc_bits <= crc_len) return -5;
+    const orc_crc_stop c = {crc_poly, crc_len, crc_bits};
+    return decode_onmsq_q(bg, Z, n_layers, max_iter, 1, alpha, beta, scale, ORC_QMAX, llr, batch, hard, iters, app, &c);
 }
 
 /* The same algorithm on a WIDE grid: channel values and messages saturate at +/-qmax grid units (e.g. 32767: 16-bit
@@ -321,7 +345,7 @@ int orc_decode_onmsq(int bg, int Z, int n_layers, int max_iter, int early_term, 
 int orc_decode_onmsq_wide(int bg, int Z, int n_layers, int max_iter, int early_term, float alpha, float beta, int scale, int qmax,
                           const double* llr, int batch, uint8_t* hard, int32_t* iters, float* app) {
     if (qmax < 1 || qmax > 32767) return -4;
-    return decode_onmsq_q(bg, Z, n_layers, max_iter, early_term, alpha, beta, scale, qmax, llr, batch, hard, iters, app);
+    return decode_onmsq_q(bg, Z, n_layers, max_iter, early_term, alpha, beta, scale, qmax, llr, batch, hard, iters, app, NULL);
 }
 
 /* beta = 0: plain normalised min-sum (the committed golden vectors of round 1 were made with it) */

@@ -34,6 +34,7 @@ def lib():
         L.orc_encode.argtypes = [i32, i32, P, i32, P]
         L.orc_decode_nmsq.argtypes = [i32, i32, i32, i32, i32, f32, i32, P, i32, P, P, P]
         L.orc_decode_onmsq.argtypes = [i32, i32, i32, i32, i32, f32, f32, i32, P, i32, P, P, P]
+        L.orc_decode_onmsq_crc.argtypes = [i32, i32, i32, i32, f32, f32, i32, C.c_uint32, i32, i32, P, i32, P, P, P]
         L.orc_decode_onmsq_wide.argtypes = [i32, i32, i32, i32, i32, f32, f32, i32, i32, P, i32, P, P, P]
         L.orc_decode_bp_flood.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32]
         L.orc_decode_bp_flood_app.argtypes = [i32, i32, i32, i32, P, i32, P, P, i32, P]
@@ -90,6 +91,20 @@ def decode_nmsq(bg, Z, llr, max_iter, n_layers=0, early_term=False, alpha=0.75, 
     app = np.zeros((B, cols * Z), np.float32) if want_app else None
     rc = lib().orc_decode_onmsq(bg, Z, n_layers, max_iter, int(early_term), alpha, beta, scale, _p(llr), B,
                                 _p(hard), _p(iters), _p(app))
+    assert rc == 0, rc
+    return (hard, iters, app) if want_app else (hard, iters)
+
+
+def decode_nmsq_crc(bg, Z, llr, max_iter, crc, n_layers=0, alpha=0.75, scale=8, want_app=False, beta=0.0):
+    """decode_nmsq with the CRC-aided stop (nrldpc_cfg.early_term = 2): crc = (poly with its x^L term, L, K')."""
+    rows, cols, kb = BG_DIMS[bg]
+    llr = np.ascontiguousarray(llr, np.float64).reshape(-1, cols * Z)
+    B = llr.shape[0]
+    hard = np.zeros((B, kb * Z), np.uint8)
+    iters = np.zeros(B, np.int32)
+    app = np.zeros((B, cols * Z), np.float32) if want_app else None
+    rc = lib().orc_decode_onmsq_crc(bg, Z, n_layers, max_iter, alpha, beta, scale, int(crc[0]), int(crc[1]), int(crc[2]), _p(llr), B,
+                                    _p(hard), _p(iters), _p(app))
     assert rc == 0, rc
     return (hard, iters, app) if want_app else (hard, iters)
 

@@ -244,6 +244,51 @@ def test_golden_fixture_on_gpu(pkg):
         assert (np.packbits(cw, axis=1) == g[name + "/cw_packed"]).all(), name
 
 
+CRC24A, CRC24B, CRC16 = (0x1864CFB, 24), (0x1800063, 24), (0x11021, 16)  # get_3gpp_crc_polynomial.m:3-14
+
+
+# bg, Z, active rows, K' (payload + CRC), generator, Es/N0 of the waterfall: split kernels with dual rows (1/384), pruned builds of
+# their own (5, 22 rows), run-time layer counts, the one-thread-per-row form (BG2 384, BG1 320), merged groups (1/256), a packed
+# size (-> run-time-Z kernel), retiring lanes (BG1 Z = 104: blocks of 52), a K' that ends inside a column, short CRC16 blocks
+@pytest.mark.parametrize("bg,Z,nl,Kp,crc,esn0", [
+    (1, 384, 0, 8448, CRC24A, -0.9), (1, 384, 5, 8448, CRC24A, 6.3), (1, 384, 17, 8000, CRC24B, 2.1), (2, 384, 22, 3840, CRC16, -0.6),
+    (2, 384, 0, 3000, CRC24B, -2.4), (1, 320, 0, 7040, CRC24B, -0.8), (1, 256, 30, 5632, CRC24A, 0.3), (2, 208, 21, 1957, CRC24B, -0.2),
+    (2, 20, 12, 116, CRC16, 1.8), (1, 104, 0, 2288, CRC24A, -0.6), (1, 88, 9, 1900, CRC24B, 4.2), (2, 7, 0, 70, CRC16, -1.5)])
+def test_crc_aided_stop(pkg, orc, bg, Z, nl, Kp, crc, esn0):
+    """nrldpc_cfg.early_term = 2: a codeword stops when its parity checks hold OR the CRC over its first K'
+    hard decisions does (and they are not all zero).  Hard decisions and iteration counts against oracle/orc_decode_onmsq_crc;
+    the stop must never come later than the parity-check stop, and must come earlier for some codewords in the waterfall.
+    Second half: the systematic bits punctured (rv_id 2 / 3 of a HARQ retransmission) -- all-zero hard decisions in the first
+    iterations must not pass for a CRC match."""
+    rng = np.random.default_rng(9000 + 7 * Z + nl)
+    rows, cols, kb = BG_DIMS[bg]
+    K, B = kb * Z, 24 + (200 // Z)
+    poly, L = crc
+    info = np.zeros((B, K), np.uint8)
+    info[:, : Kp - L] = rng.integers(0, 2, (B, Kp - L), dtype=np.uint8)
+    for b in range(B):  # payload followed by its CRC (NRLDPCEncoder.m:70-89, 92-124), fillers = 0 behind
+        r = orc.crc(poly, L, info[b, : Kp - L])
+        info[b, Kp - L: Kp] = (r >> np.arange(L - 1, -1, -1)) & 1
+        assert orc.crc(poly, L, info[b, :Kp]) == 0
+    cw = orc.encode(bg, Z, info)
+    for punct in (False, True):
+        llr = awgn_llr(rng, cw, esn0 + (2.5 if punct else 0.0), np.float32, Z)
+        llr[:, Kp:K] = np.inf  # fillers (NRLDPCDecoder.m:264)
+        if punct:
+            llr[:, : (kb // 2) * Z] = 0
+        c = pkg.Codec(bg, Z, max_iter=20, n_layers=nl, llr_dtype=np.float32, crc=(poly, L, Kp))
+        hard, it = c.decode(llr, want_iters=True)
+        c1 = pkg.Codec(bg, Z, max_iter=20, n_layers=nl, early_term=True, llr_dtype=np.float32)
+        hard1, it1 = c1.decode(llr, want_iters=True)
+        c.close(); c1.close()
+        ho, io = orc.decode_nmsq_crc(bg, Z, llr.astype(np.float64), 20, (poly, L, Kp), n_layers=nl, **rule_kw(c))
+        assert (hard == ho).all(), "hard decisions differ"
+        assert (it == io).all(), "iteration counts differ"
+        assert (it <= it1).all()
+        if not punct:
+            assert (it < it1).any(), "no codeword stopped on its CRC before its parity checks held"
+
+
 @pytest.mark.parametrize("bg,Z,B", [(1, 384, 700), (2, 7, 33), (1, 3, 5), (2, 96, 9000), (1, 64, 1)])
 def test_bit_packed_hard_output(pkg, orc, bg, Z, B):
     """nrldpc_decode_packed (ABI revision 4): the same decisions as nrldpc_decode, bit k of a codeword in byte k // 8 at bit

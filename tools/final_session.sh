@@ -1,8 +1,8 @@
 #!/bin/bash
-# The measurement set behind profiles/r03_*: GPU tests, bench line, every BASELINE configuration, all lifting sizes, chain stages
+# The measurement set behind profiles/r04_*: GPU tests, bench line, every BASELINE configuration, all lifting sizes, chain stages
 # (+ their kernel trace), Monte-Carlo loop, host path, rocprofv3 kernel trace + PMC passes of the bench command.
-# TAG=r03 bash tools/final_session.sh ; then on the build box: python tools/collect_profiles.py r03
-TAG=${TAG:-r03}
+# TAG=r04 bash tools/final_session.sh ; then on the build box: python tools/collect_profiles.py r04
+TAG=${TAG:-r04}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 if [ -z "$SKIP_TESTS" ]; then

@@ -51,13 +51,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bg", type=int, default=1)
     ap.add_argument("--z", type=int, default=384)
-    ap.add_argument("--kernel-ms", type=float, default=3.67, help="measured fixed-25 kernel time of the batch below")
+    ap.add_argument("--kernel-ms", type=float, default=None, help="measured fixed-25 kernel time of the batch below; default: "
+                    "roofline.kernel_ms of --bench-line (no number is assumed: without either, no fraction is printed)")
+    ap.add_argument("--bench-line", default=os.path.join(ROOT, "gpurun_out", "bench_line_noprofile.json"),
+                    help="a bench.py line of the same build and session to take the kernel time from")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=25)
     ap.add_argument("--launch-invariant-ms", type=float, default=0.06)
     ap.add_argument("--form", default="split", choices=("row", "split"))
     ap.add_argument("--json", default=None, help="also write the totals (with nrldpc_kernel_id) for bench.py")
     a = ap.parse_args()
+    kms_src = "--kernel-ms"
+    if a.kernel_ms is None and os.path.exists(a.bench_line):
+        try:
+            import json as _json
+            a.kernel_ms = float(_json.load(open(a.bench_line))["roofline"]["kernel_ms"])
+            kms_src = "roofline.kernel_ms of " + os.path.relpath(a.bench_line, ROOT)
+        except Exception:
+            a.kernel_ms = None
     tab = rates()
     with tempfile.TemporaryDirectory() as td:
         co = os.path.join(td, "k.co")
@@ -138,11 +149,14 @@ def main():
     print()
     print("VALU-bound time of the timed launch: %.1f ns x %.1f row blocks per SIMD (2 codewords per CU) x %d iterations x %.1f rounds = %.3f ms" % (
         total, wps, a.iters, rounds, valu_ms))
-    print("measured kernel time %.3f ms (of which %.2f ms launch-invariant: workgroup start, LLR ingest, write-back)" % (a.kernel_ms, a.launch_invariant_ms))
-    print("cycle-weighted VALU roofline fraction: %.3f of the kernel, %.3f of its iteration part" % (
-        valu_ms / a.kernel_ms, valu_ms / (a.kernel_ms - a.launch_invariant_ms)))
-    print("(compare SQ_ACTIVE_INST_VALU / busy cycles in profiles/r03_bench_pmc_summary.json; the 2-cycle-per-op VALU-issue fraction")
-    print(" of the bench line prices every op at the full rate)")
+    if a.kernel_ms:
+        print("measured kernel time %.3f ms (%s; of which %.2f ms launch-invariant: workgroup start, LLR ingest, write-back)" % (
+            a.kernel_ms, kms_src, a.launch_invariant_ms))
+        print("cycle-weighted VALU roofline fraction: %.3f of the kernel, %.3f of its iteration part" % (
+            valu_ms / a.kernel_ms, valu_ms / (a.kernel_ms - a.launch_invariant_ms)))
+    else:
+        print("(no measured kernel time given: bench.py divides by the time it measures itself -- roofline.cycle_weighted)")
+    print("(the 2-cycle-per-op VALU-issue fraction of the bench line prices every op at the full rate)")
     if a.json:
         import importlib, json
         sys.path.insert(0, ROOT)
