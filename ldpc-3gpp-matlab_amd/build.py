@@ -31,6 +31,8 @@ Z64P_BG2 = Z64P_BG1[:-4]
 Z64P_PAIRS = [(1, z) for z in Z64P_BG1] + [(2, z) for z in Z64P_BG2]
 # = NRLDPC_Z64P_NL_LIST: (BG, Z, active layers) with packed builds of their own
 Z64P_NL = [(2, 20, 12)]
+# = NRLDPC_Z64PR_LIST: (BG, Z, row waves) with pipelined one-thread-per-row builds in the packed geometry
+Z64PR = [(2, 88, 6), (2, 96, 6), (2, 176, 6), (2, 352, 6), (2, 144, 5), (2, 160, 5), (2, 288, 5), (2, 320, 5)]
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7), (2, 208, 21)]
 HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h", "nrldpc_hostpath.h"]
@@ -140,6 +142,8 @@ def build_lib(force=False, verbose=False, jobs=None):
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64P_PAIRS]
     units += [(os.path.join(CSRC, Z64P_SOURCE), os.path.join(OBJDIR, "z64p_%d_%d_nl%d.o" % (bg, z, nl)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64P_NL]
+    units += [(os.path.join(CSRC, Z64P_SOURCE), os.path.join(OBJDIR, "z64pr_%d_%d.o" % (bg, z)),
+               ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64P_ROW=1", "-DNRLDPC_Z64P_RW=%d" % rw]) for bg, z, rw in Z64PR]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64_NL]
     # An object is reused only when it was compiled from exactly these inputs: contents of its source and of every header

@@ -693,7 +693,16 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     struct Group { std::vector<nrldpc::DecArgs> args; std::vector<int32_t> start; size_t lds = 0; int grid = 0; };
     Group g[2][2];
     std::vector<int> routed;
-    for (int i = 0; i < n; ++i) {
+    // The shared launches take their configurations LARGEST lifting size first: a workgroup's run time grows with Z (more waves
+    // per codeword, longer prologue), the dispatcher hands workgroups out in index order, and a launch ends when its last
+    // workgroup does -- the long ones must not be the ones that start last (NRLDPC_MULTI_KEEP_ORDER=1: the caller's order, A/B).
+    static const bool keep_order = getenv("NRLDPC_MULTI_KEEP_ORDER") != nullptr;
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    if (!keep_order)
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hs[x]->sched.Z > hs[y]->sched.Z; });
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[(size_t)oi];
         if (batch[i] == 0) continue;
         nrldpc_codec* h = hs[i];
         const nrldpc::Schedule& s = h->sched;
@@ -846,7 +855,8 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             if (!h->xs[i]) HIP_TRY(hipStreamCreateWithFlags(&h->xs[i], hipStreamNonBlocking));
         // Chunk k = codewords [starts[k], starts[k+1]).  The first chunk's copy + H2D is the one stretch of a call in which the
         // device has nothing to do, so a call of several rounds opens with two half chunks (one workgroup per CU each).
-        static const bool env_ramp = !(getenv("NRLDPC_HOST_RAMP") && atoi(getenv("NRLDPC_HOST_RAMP")) == 0); // A/B
+        // (NRLDPC_HOST_RAMP=1; off by default: measured +-4 % either way on the fp16 path, within the run-to-run spread)
+        static const bool env_ramp = getenv("NRLDPC_HOST_RAMP") && atoi(getenv("NRLDPC_HOST_RAMP")) != 0;
         std::vector<int> starts(1, 0);
         for (int pos = 0, k = 0; pos < batch; ++k) {
             const int want = (env_ramp && k < 2 && chunk >= 512 && batch >= 3 * chunk) ? chunk / 2 : chunk;

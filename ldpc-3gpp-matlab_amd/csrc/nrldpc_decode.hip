@@ -210,7 +210,8 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
             if (tid <= a.ncw) flags[tid] = 0; // flags[ncw] = "some codeword of this workgroup still fails"
             // CRC-aided stop (early_term = 2): per codeword CRC_SLOTS words behind the flags (16-byte aligned)
             int* crc_slots = flags + ((a.ncw + 1 + 3) & ~3) + cwl * CRC_SLOTS;
-            if (a.crc_bits && tid < a.ncw * CRC_SLOTS) flags[((a.ncw + 1 + 3) & ~3) + tid] = 0;
+            if (a.crc_bits)
+                for (int i = tid; i < a.ncw * CRC_SLOTS; i += (int)blockDim.x) flags[((a.ncw + 1 + 3) & ~3) + i] = 0;
             __syncthreads();
             if (!done && a.crc_bits) { // every thread folds the information bits at its own ring position z of each column
                 CrcFold f;
@@ -368,10 +369,19 @@ hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes
         NRLDPC_Z64P_NL_LIST(NRLDPC_Z64P_NL_CASE)
 #undef NRLDPC_Z64P_NL_CASE
     }
+    static const bool no_packed_row = getenv("NRLDPC_NO_PACKED_ROW") != nullptr; // A/B against the block-geometry / run-time-Z kernels
+    if (!force_generic && !no_packed && !no_packed_row && !a.app && !crc) { // packed geometry, pipelined one-thread-per-row builds
+#define NRLDPC_Z64PR_CASE(b, z, rw) if (bg == b && a.Z == z) return launch_decode_z64pr_##b##_##z(a, stream);
+        NRLDPC_Z64PR_LIST(NRLDPC_Z64PR_CASE)
+#undef NRLDPC_Z64PR_CASE
+    }
     // the packed builds: hard output; every row active, or any other layer count as a run-time prefix (NL_RT; NRLDPC_NO_RT=1
     // sends those to the kernels that served them before -- A/B)
     static const bool no_rt = getenv("NRLDPC_NO_RT") != nullptr;
-    if (!a.app && !crc && (a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) || !no_rt) && has_z64p_kernel(bg, a.Z, a.early_term != 0)) {
+    // (BG2 with pruned rows AND the parity stop stays with the general kernel of this geometry below: 8-18 % faster there,
+    // profiles/r04_bench_nl_packed.txt)
+    const bool all_rows = a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS);
+    if (!a.app && !crc && (all_rows || (!no_rt && !(bg == 2 && a.early_term))) && has_z64p_kernel(bg, a.Z, a.early_term != 0)) {
 #define NRLDPC_Z64P_CASE(b, z) if (bg == b && a.Z == z) return launch_decode_z64p_##b##_##z(a, stream);
         NRLDPC_Z64P_LIST(NRLDPC_Z64P_CASE)
 #undef NRLDPC_Z64P_CASE

@@ -251,10 +251,17 @@ template <int BG, int ZC> constexpr int z64pg_wpe() {
     return by_lds >= cap ? cap : by_lds >= 1 ? by_lds : 1;
 }
 
-template <int BG, int ZC>
+// MODE 0: the general kernel described above.  MODE 1 / 2 ("row form" of the packed geometry, nrldpc_decode_z64pr_*): the same
+// workgroup -- one thread per check row, RW waves, NCW whole codewords -- with the SOFTWARE-PIPELINED layer loop of the block
+// geometry's one-thread-per-row kernel (pipeline_z64: fixed iteration count / parity-check stop), hard output only; NL = every
+// row, or NL_RT (a run-time prefix).  For BG2's large lifting sizes that do not split into full waves (11 x 2^k: 88, 176, 352
+// as 352 row lanes; 96 as 4 x 96 = 384): BG2's one-thread-per-row form fits 80 registers, so four 6-wave workgroups fill a
+// CU exactly as Z = 384's do, with 92-100 % of the lanes at work instead of 69-75 %.
+template <int BG, int ZC, int MODE = 0, int NL = BGT<BG>::ROWS>
 __global__ __launch_bounds__(z64p_rw(BG, ZC) * 64, (z64pg_wpe<BG, ZC>())) void nrldpc_decode_z64pg_kernel(const DecArgs a) {
-    using G = Z64P<BG, ZC>;
+    using G = Z64P<BG, ZC, NL>;
     using LG = LayerGroups<BG>;
+    static_assert(MODE != 0 || NL == BGT<BG>::ROWS, "the general kernel reads its layer count at run time from the all-rows tables");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int rw = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -351,6 +358,55 @@ __global__ __launch_bounds__(z64p_rw(BG, ZC) * 64, (z64pg_wpe<BG, ZC>())) void n
 
     uint32_t esign_lo = 0, esign_hi = 0;
     bool done = !present; // per lane = per codeword
+    // parity check of every codeword of the workgroup; a codeword that passes leaves now (write_out); true: nobody is left
+    auto parity_and_retire = [&](int it) -> bool {
+        if (tid <= G::NCW) flags[tid] = 0;
+        __syncthreads();
+        uint32_t bad = 0;
+        bool stop = false; // wave-uniform
+        static_for<G::ROWS>([&](auto lc) {
+            constexpr int L = decltype(lc)::value;
+            if (!stop && L < launder(a.n_layers)) {
+                bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                if constexpr (L < 4 || (L % 4) == 3) {
+                    if (bad && !done) flags[c] = 1;
+                    stop = __all((int)(bad | (uint32_t)done | (uint32_t)__atomic_load_n(&flags[c], __ATOMIC_RELAXED))) != 0;
+                }
+            }
+        });
+        if (bad && !done) { flags[c] = 1; flags[G::NCW] = 1; }
+        __syncthreads();
+        if (!done && flags[c] == 0) {
+            done = true;
+            write_out(it);
+        }
+        return __builtin_amdgcn_readfirstlane(flags[G::NCW]) == 0;
+    };
+    if constexpr (MODE != 0) {
+        constexpr bool ETP = MODE == 2;
+        const float cap = (127.49f + a.beta) / a.alpha; // see LayerZ64::track3
+        DecArgs av = a;                                  // alpha, 2^23 - beta as VGPR values (the one-thread-per-row kernel's choice)
+        av.beta = 8388608.0f - a.beta;
+        asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
+        GroupZ64<BG, ZC, 0, NL> g0;
+        g0.template loads<false>(lds, R);
+        g0.template track<false>(st, cap);
+        for (int it = 1; it <= a.max_iter; ++it) {
+            if constexpr (ETP) { esign_lo = 0; esign_hi = 0; }
+            GroupZ64<BG, ZC, 0, NL> nx;
+            pipeline_z64<BG, ZC, 0, ETP, NL>(g0, nx, st, lds, R, RA, RB, rw, av, cap, esign_lo, esign_hi);
+            if constexpr (G::RT) { // wherever the iteration ended: group 0's early part (none of its edges is early then)
+                nx.template loads<false>(lds, R);
+                nx.template track<false>(st, cap);
+            }
+            g0 = nx;
+            if constexpr (ETP) {
+                if (parity_and_retire(it)) break;
+            }
+        }
+        if constexpr (!ETP) __syncthreads(); // the last group's writes
+        if (!done) write_out(a.max_iter);
+    } else {
     for (int it = 1; it <= a.max_iter; ++it) {
         esign_lo = 0; esign_hi = 0;
         float* app_ext = done ? nullptr : app_row; // a converged codeword keeps iterating, but its soft output is final
@@ -372,36 +428,15 @@ __global__ __launch_bounds__(z64p_rw(BG, ZC) * 64, (z64pg_wpe<BG, ZC>())) void n
                 }
             }
         });
-        if (a.early_term) {
-            if (tid <= G::NCW) flags[tid] = 0;
-            __syncthreads();
-            uint32_t bad = 0;
-            bool stop = false; // wave-uniform
-            static_for<G::ROWS>([&](auto lc) {
-                constexpr int L = decltype(lc)::value;
-                if (!stop && L < launder(a.n_layers)) {
-                    bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
-                    if constexpr (L < 4 || (L % 4) == 3) {
-                        if (bad && !done) flags[c] = 1;
-                        stop = __all((int)(bad | (uint32_t)done | (uint32_t)__atomic_load_n(&flags[c], __ATOMIC_RELAXED))) != 0;
-                    }
-                }
-            });
-            if (bad && !done) { flags[c] = 1; flags[G::NCW] = 1; }
-            __syncthreads();
-            if (!done && flags[c] == 0) {
-                done = true;
-                write_out(it);
-            }
-            if (__builtin_amdgcn_readfirstlane(flags[G::NCW]) == 0) break;
-        }
+        if (a.early_term && parity_and_retire(it)) break;
     }
     if (!done) write_out(a.max_iter);
+    }
 }
 
-template <int BG, int ZC> static hipError_t launch_z64pg(const DecArgs& a, hipStream_t s) {
-    using G = Z64P<BG, ZC>;
-    auto k = nrldpc_decode_z64pg_kernel<BG, ZC>;
+template <int BG, int ZC, int MODE = 0, int NL = BGT<BG>::ROWS> static hipError_t launch_z64pg(const DecArgs& a, hipStream_t s) {
+    using G = Z64P<BG, ZC, NL>;
+    auto k = nrldpc_decode_z64pg_kernel<BG, ZC, MODE, NL>;
     constexpr size_t lds = G::lds_bytes();
     static bool attr_set[64] = {};
     int dev = 0;
@@ -413,6 +448,12 @@ template <int BG, int ZC> static hipError_t launch_z64pg(const DecArgs& a, hipSt
     }
     hipLaunchKernelGGL(k, dim3((a.batch + G::NCW - 1) / G::NCW), dim3(G::RW * 64), lds, s, a);
     return hipGetLastError();
+}
+
+// the pipelined one-thread-per-row builds of the packed geometry (MODE 1 / 2 above): hard output, any layer count
+template <int BG, int ZC> static hipError_t launch_z64pr(const DecArgs& a, hipStream_t s) {
+    if (a.n_layers != BGT<BG>::ROWS) return a.early_term ? launch_z64pg<BG, ZC, 2, NL_RT>(a, s) : launch_z64pg<BG, ZC, 1, NL_RT>(a, s);
+    return a.early_term ? launch_z64pg<BG, ZC, 2>(a, s) : launch_z64pg<BG, ZC, 1>(a, s);
 }
 
 // hard output only, every row active or the layer count of the build (the caller checks: anything else is the run-time-Z kernel's)

@@ -14,7 +14,12 @@
 #define NRLDPC_CAT(a, b, c) NRLDPC_CAT_(a, b, c)
 
 namespace nrldpc {
-#ifdef NRLDPC_Z64_NL
+#ifdef NRLDPC_Z64P_ROW
+// -DNRLDPC_Z64P_ROW=1 (with -DNRLDPC_Z64P_RW=<waves>): the pipelined one-thread-per-row builds of this (BG, Z) only (NRLDPC_Z64PR_LIST)
+hipError_t NRLDPC_CAT(launch_decode_z64pr_, NRLDPC_Z64_BG, NRLDPC_Z64_Z)(const DecArgs& a, hipStream_t stream) {
+    return launch_z64pr<NRLDPC_Z64_BG, NRLDPC_Z64_Z>(a, stream);
+}
+#elif defined(NRLDPC_Z64_NL)
 // -DNRLDPC_Z64_NL=<count>: the builds of one pruned layer count (NRLDPC_Z64P_NL_LIST)
 #define NRLDPC_CAT4_(a, b, c, d) a##b##_##c##_nl##d
 #define NRLDPC_CAT4(a, b, c, d) NRLDPC_CAT4_(a, b, c, d)

@@ -61,12 +61,19 @@ NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
     X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 7) X(2, 8) X(2, 9) X(2, 10) X(2, 11) X(2, 12) X(2, 13) X(2, 14) X(2, 15) X(2, 16) X(2, 18) X(2, 20) X(2, 22) X(2, 24) X(2, 26) X(2, 28) X(2, 30) X(2, 32) X(2, 36) X(2, 40) X(2, 44) X(2, 48) X(2, 52) X(2, 56) X(2, 72) X(2, 80)
 // ... of which these serve fixed iteration counts only: with the parity-check stop the block-geometry split build of the
 // same size is faster (BG2 Z = 52: 0.44 against 0.54 ms; at 25 fixed iterations the packed build wins by 9 %)
-#define NRLDPC_Z64P_NOT_ET(X) X(2, 52)
+// (BG1 Z = 176: 1.585 against 1.485 ms with the parity stop, 3.98 against 4.17 ms at 25 fixed iterations)
+#define NRLDPC_Z64P_NOT_ET(X) X(2, 52) X(1, 176)
 #define NRLDPC_Z64P_DECL(bg, z) hipError_t launch_decode_z64p_##bg##_##z(const DecArgs& a, hipStream_t stream); \
     hipError_t launch_decode_z64pg_##bg##_##z(const DecArgs& a, hipStream_t stream);
 NRLDPC_Z64P_LIST(NRLDPC_Z64P_DECL)
 #undef NRLDPC_Z64P_DECL
 bool has_z64p_kernel(int bg, int Z, bool early_term);
+// ... and the packed geometry's pipelined one-thread-per-row builds (nrldpc_decode_z64p.h, MODE 1 / 2; -DNRLDPC_Z64P_ROW): (BG, Z,
+// row waves per workgroup) -- BG2's large lifting sizes that do not split into full waves
+#define NRLDPC_Z64PR_LIST(X) X(2, 88, 6) X(2, 96, 6) X(2, 176, 6) X(2, 352, 6) X(2, 144, 5) X(2, 160, 5) X(2, 288, 5) X(2, 320, 5)
+#define NRLDPC_Z64PR_DECL(bg, z, rw) hipError_t launch_decode_z64pr_##bg##_##z(const DecArgs& a, hipStream_t stream);
+NRLDPC_Z64PR_LIST(NRLDPC_Z64PR_DECL)
+#undef NRLDPC_Z64PR_DECL
 // ... and pruned layer counts with packed builds of their own: BASELINE.json configs[0] (BG2, A = 100, R = 1/3: Z = 20, 12 rows),
 // the operating point of the reference's plot_BLER_vs_SNR.m defaults
 #define NRLDPC_Z64P_NL_LIST(X) X(2, 20, 12)

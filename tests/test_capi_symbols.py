@@ -183,10 +183,11 @@ def test_kernel_lists_of_the_build_and_of_the_dispatch_agree():
 
     assert sorted(pairs("NRLDPC_Z64_LIST")) == sorted(bld.Z64_PAIRS)
     assert sorted(pairs("NRLDPC_Z64P_LIST")) == sorted(bld.Z64P_PAIRS)
+    assert sorted(pairs("NRLDPC_Z64PR_LIST")) == sorted(bld.Z64PR)
     assert sorted(pairs("NRLDPC_Z64_NL_LIST")) == sorted(bld.Z64_NL)
     assert sorted(pairs("NRLDPC_Z64P_NL_LIST")) == sorted(bld.Z64P_NL)
     assert set(pairs("NRLDPC_Z64P_NOT_ET")) <= set(bld.Z64P_PAIRS)
     # a packed size that has no block-geometry unit falls back to the run-time-Z kernel for pruned rows / soft output: fine;
     # but every lifting size of TS 38.212 must be a legal Z for it
     all_z = sorted(a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384)
-    assert all(z in all_z for _, z in bld.Z64_PAIRS + bld.Z64P_PAIRS)
+    assert all(z in all_z for _, z in bld.Z64_PAIRS + bld.Z64P_PAIRS + [(b, z) for b, z, _ in bld.Z64PR])
