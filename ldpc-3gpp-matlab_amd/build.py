@@ -32,7 +32,7 @@ Z64P_PAIRS = [(1, z) for z in Z64P_BG1] + [(2, z) for z in Z64P_BG2]
 # = NRLDPC_Z64P_NL_LIST: (BG, Z, active layers) with packed builds of their own
 Z64P_NL = [(2, 20, 12)]
 # = NRLDPC_Z64PR_LIST: (BG, Z, row waves) with pipelined one-thread-per-row builds in the packed geometry
-Z64PR = [(2, 88, 6), (2, 96, 6), (2, 176, 6), (2, 352, 6), (2, 144, 5), (2, 160, 5), (2, 288, 5), (2, 320, 5)]
+Z64PR = []  # (measured slower than the block-geometry kernels for BG2 88 ... 352: nrldpc_kernels.h)
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7), (2, 208, 21)]
 HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h", "nrldpc_hostpath.h"]

@@ -693,16 +693,9 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     struct Group { std::vector<nrldpc::DecArgs> args; std::vector<int32_t> start; size_t lds = 0; int grid = 0; };
     Group g[2][2];
     std::vector<int> routed;
-    // The shared launches take their configurations LARGEST lifting size first: a workgroup's run time grows with Z (more waves
-    // per codeword, longer prologue), the dispatcher hands workgroups out in index order, and a launch ends when its last
-    // workgroup does -- the long ones must not be the ones that start last (NRLDPC_MULTI_KEEP_ORDER=1: the caller's order, A/B).
-    static const bool keep_order = getenv("NRLDPC_MULTI_KEEP_ORDER") != nullptr;
-    std::vector<int> order((size_t)n);
-    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
-    if (!keep_order)
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hs[x]->sched.Z > hs[y]->sched.Z; });
-    for (int oi = 0; oi < n; ++oi) {
-        const int i = order[(size_t)oi];
+    // (Ordering the shared launches' configurations largest lifting size first -- so that the longest workgroups do not start
+    // last -- was measured on BASELINE configs[3]: 0.66 ms against 0.61-0.63 ms in the caller's order, twice; not kept.)
+    for (int i = 0; i < n; ++i) {
         if (batch[i] == 0) continue;
         nrldpc_codec* h = hs[i];
         const nrldpc::Schedule& s = h->sched;

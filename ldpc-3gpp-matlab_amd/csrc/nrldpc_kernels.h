@@ -69,8 +69,11 @@ NRLDPC_Z64P_LIST(NRLDPC_Z64P_DECL)
 #undef NRLDPC_Z64P_DECL
 bool has_z64p_kernel(int bg, int Z, bool early_term);
 // ... and the packed geometry's pipelined one-thread-per-row builds (nrldpc_decode_z64p.h, MODE 1 / 2; -DNRLDPC_Z64P_ROW): (BG, Z,
-// row waves per workgroup) -- BG2's large lifting sizes that do not split into full waves
-#define NRLDPC_Z64PR_LIST(X) X(2, 88, 6) X(2, 96, 6) X(2, 176, 6) X(2, 352, 6) X(2, 144, 5) X(2, 160, 5) X(2, 288, 5) X(2, 320, 5)
+// row waves per workgroup).  EMPTY: built for BG2's large lifting sizes that do not split into full waves (88, 96, 176, 352 with
+// 6 row waves; 144, 160, 288, 320 with 5), bit-exact, and slower than the block-geometry kernels at every one of them
+// (profiles/r04_packed_row_bg2.txt: +5...+25 % at 25 fixed iterations, +3...+56 % with the parity stop) -- the doubled rings
+// leave a CU three 6-wave workgroups where Z = 384's block geometry holds four.  The kernel modes stay for the next shape.
+#define NRLDPC_Z64PR_LIST(X)
 #define NRLDPC_Z64PR_DECL(bg, z, rw) hipError_t launch_decode_z64pr_##bg##_##z(const DecArgs& a, hipStream_t stream);
 NRLDPC_Z64PR_LIST(NRLDPC_Z64PR_DECL)
 #undef NRLDPC_Z64PR_DECL

@@ -14,6 +14,15 @@ python tools/bench_chain.py > gpurun_out/chain.log 2>&1
 python tools/bench_montecarlo.py > gpurun_out/mc.log 2>&1
 python tools/bench_all_z.py > gpurun_out/allz.log 2>&1
 if [ -z "$SKIP_HOST" ]; then python tools/bench_host_path.py > gpurun_out/hostpath.log 2>&1; fi
+# round 4: pruned layer counts (three routes), CRC-aided stop, BASELINE configs[4] as the bench leg at N = 1, host-path phase trace
+python tools/bench_nl.py default > gpurun_out/nl_default.log 2>&1
+NRLDPC_NO_PRUNED_PIPELINE=1 python tools/bench_nl.py rt > gpurun_out/nl_rt.log 2>&1
+NRLDPC_NO_PRUNED_PIPELINE=1 NRLDPC_NO_RT=1 python tools/bench_nl.py general > gpurun_out/nl_general.log 2>&1
+python tools/bench_nl.py --merge > gpurun_out/bench_nl.txt 2>&1
+python tools/bench_crc_stop.py > gpurun_out/crc_stop.log 2>&1
+python bench.py --cfg5 --steps 10 --warmup 3 --cpu-sample 0 --no-e2e --no-early-term 2>/dev/null | tail -1 > gpurun_out/bench_cfg5_n1.json
+NRLDPC_HOST_TRACE=1 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-early-term 2> gpurun_out/host_trace.err | tail -1 > gpurun_out/bench_host_trace_line.json
+grep "host path" gpurun_out/host_trace.err > gpurun_out/host_trace.txt
 bash tools/profile_gpu.sh $TAG > gpurun_out/profile.log 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_chain -o chain -- python $GRAFT_REPO_ROOT/tools/bench_chain.py > $GRAFT_REPO_ROOT/gpurun_out/prof_chain.log 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cfg -o cfg -- python $GRAFT_REPO_ROOT/tools/bench_configs.py > $GRAFT_REPO_ROOT/gpurun_out/prof_cfg.log 2>&1 )
