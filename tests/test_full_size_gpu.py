@@ -66,7 +66,7 @@ def test_headline_batch_every_codeword_against_the_oracle(pkg, orc):
         assert 0.0 < (ho != info).any(1).mean() < 0.9  # the batch straddles the waterfall
 
 
-def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):
+def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):
     # G for R = 1/5 ... 2/3 -> active layers; Es/N0 about 1 dB above each waterfall
     for E, nl, esn0 in ((19120, 42, -3.0), (15296, 32, -2.0), (11472, 22, -0.5), (9560, 17, 0.5), (7648, 12, 2.0),
                         (6374, 9, 3.2), (5736, 7, 4.5)):  # all seven rates of BASELINE configs[2]
