@@ -265,9 +265,9 @@ CASES_DEMO = [
     # the script's own defaults (plot_BLER_vs_SNR.m:29-41): two code blocks of BG2 Z = 208, 8 iterations
     ("demo A=3842 BG2 R=1/3 QPSK 8it rv[0]", 3842, 1 / 3, 2, "QPSK", (0,), 8, [-1.0, -0.5, 0.0, 0.5, 1.0], 512),
     # the same point sent at R = 2/3 with up to four HARQ transmissions (:38's rv_id_sequence option, I_HARQ = 1 as :99)
-    ("demo A=3842 BG2 R=2/3 QPSK 8it rv[0 2 3 1]", 3842, 2 / 3, 2, "QPSK", (0, 2, 3, 1), 8, [-3.0, -2.5, -2.0, -1.5, -1.0], 512),
+    ("demo A=3842 BG2 R=2/3 QPSK 8it rv[0 2 3 1]", 3842, 2 / 3, 2, "QPSK", (0, 2, 3, 1), 8, [-4.75, -4.25, -3.75, -3.25, -2.75, -2.25], 512),
     # one higher-order point: exact LLRs of the 64QAM demapper (NRDemodulator.m:80)
-    ("demo A=3842 BG2 R=1/2 64QAM 8it rv[0]", 3842, 1 / 2, 2, "64QAM", (0,), 8, [9.0, 9.5, 10.0, 10.5, 11.0], 512),
+    ("demo A=3842 BG2 R=1/2 64QAM 8it rv[0]", 3842, 1 / 2, 2, "64QAM", (0,), 8, [10.75, 11.25, 11.75, 12.25, 12.75, 13.25, 13.75, 14.25], 512),
 ]
 
 

@@ -77,7 +77,9 @@ def main():
                                "--no-gpu-bundle-output", "-c", os.path.join(CSRC, "nrldpc_decode_z64_inst.hip"), "-o", co])
         dis = subprocess.check_output([OBJDUMP, "-d", co], text=True)
     # the fixed-iteration build: row form <BG, Z, NCWG, FULL=1, PLAIN=1, ETP=0, NL>; split form <BG, Z, ETP=0, NL>
-    pat = (r"nrldpc_decode_z64_kernelILi%dELi%dELi\d+ELb1ELb1ELb0E" if a.form == "row" else r"nrldpc_decode_z64s_kernelILi%dELi%dELb0E") % (a.bg, a.z)
+    # (... with every row active: NL = 46 / 42 -- the unit also holds the builds with a run-time layer count, NL = 0)
+    rows_all = {1: 46, 2: 42}[a.bg]
+    pat = (r"nrldpc_decode_z64_kernelILi%dELi%dELi\d+ELb1ELb1ELb0ELi%dE" if a.form == "row" else r"nrldpc_decode_z64s_kernelILi%dELi%dELb0ELi%dE") % (a.bg, a.z, rows_all)
     cur, body = None, []
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
