@@ -321,10 +321,8 @@ template <int BG, int ZC, int NL> constexpr int z64s_variant() {
     return (z64s_dual<BG, ZC, NL>() ? SPLIT_DUAL : 0) | (z64s_single<BG, ZC, NL>() ? SPLIT_SINGLE : 0);
 }
 // the barrier-group table of a kernel form (H < 0: one thread per check row)
-// (z64s_single: the split builds with a run-time layer count always have one-layer groups; the one-thread-per-row builds keep
-// the merged groups -- 28 / 32 barriers per iteration instead of 42 / 46 -- and a layer count that cuts a group switches the
-// group's later layers off at run time, GroupZ64::CUT)
-template <int BG, int ZC, int NL, int H> using LGof = LayerGroups<BG, NL, (H >= 0 && z64s_single<BG, ZC, NL>())>;
+// (a run-time layer count may end an iteration after any layer, so its builds -- both forms -- have one-layer groups)
+template <int BG, int ZC, int NL, int H> using LGof = LayerGroups<BG, NL, (NL == NL_RT || (H >= 0 && z64s_single<BG, ZC, NL>()))>;
 
 // One base-graph layer for this thread's check row, split into phases so that the layers of a
 // column-disjoint barrier group can issue all their LDS reads first and share one mirror dispatch.
@@ -646,37 +644,33 @@ template <int BG, int ZC, int GI, int NL = BGT<BG>::ROWS, int H = -1> struct Gro
     std::conditional_t<(N > 1), LayerZ64<BG, ZC, (N > 1 ? GS + 1 : GS), true, NL, H>, NoLayer> l1;
     std::conditional_t<(N > 2), LayerZ64<BG, ZC, (N > 2 ? GS + 2 : GS), true, NL, H>, NoLayer> l2;
 
-    // Run-time layer count with merged groups: the count may cut this group -- its layers are column-disjoint, so the active
-    // prefix of the group is processed exactly as the whole group would be; `nl` switches the later layers off (scalar branches).
-    static constexpr bool CUT = NL == NL_RT && N > 1;
-    static constexpr int NO_CUT = 0x7fffffff;
-    template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], int nl = NO_CUT) {
+    template <bool LATE> __device__ __forceinline__ void loads(const char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE]) {
         l0.template load_part<LATE>(lds, R);
-        if constexpr (N > 1) { if (!CUT || GS + 1 < nl) l1.template load_part<LATE>(lds, R); }
-        if constexpr (N > 2) { if (!CUT || GS + 2 < nl) l2.template load_part<LATE>(lds, R); }
+        if constexpr (N > 1) l1.template load_part<LATE>(lds, R);
+        if constexpr (N > 2) l2.template load_part<LATE>(lds, R);
     }
-    template <bool LATE, bool XF = false, class St> __device__ __forceinline__ void track(const St& st, float cap, int nl = NO_CUT) {
+    template <bool LATE, bool XF = false, class St> __device__ __forceinline__ void track(const St& st, float cap) {
         l0.template track_part<LATE, XF>(st, cap);
-        if constexpr (N > 1) { if (!CUT || GS + 1 < nl) l1.template track_part<LATE, XF>(st, cap); }
-        if constexpr (N > 2) { if (!CUT || GS + 2 < nl) l2.template track_part<LATE, XF>(st, cap); }
+        if constexpr (N > 1) l1.template track_part<LATE, XF>(st, cap);
+        if constexpr (N > 2) l2.template track_part<LATE, XF>(st, cap);
     }
-    template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], const DecArgs& a, int nl = NO_CUT) {
+    template <class St> __device__ __forceinline__ void finish(St& st, char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], const DecArgs& a) {
         l0.finish(st, lds, R, a);
-        if constexpr (N > 1) { if (!CUT || GS + 1 < nl) l1.finish(st, lds, R, a); }
-        if constexpr (N > 2) { if (!CUT || GS + 2 < nl) l2.finish(st, lds, R, a); }
+        if constexpr (N > 1) l1.finish(st, lds, R, a);
+        if constexpr (N > 2) l2.finish(st, lds, R, a);
     }
-    __device__ __forceinline__ void ext(const DecArgs& a, uint32_t& esign_lo, uint32_t& esign_hi, int nl = NO_CUT) const {
+    __device__ __forceinline__ void ext(const DecArgs& a, uint32_t& esign_lo, uint32_t& esign_hi) const {
         l0.ext(a, esign_lo, esign_hi, nullptr);
-        if constexpr (N > 1) { if (!CUT || GS + 1 < nl) l1.ext(a, esign_lo, esign_hi, nullptr); }
-        if constexpr (N > 2) { if (!CUT || GS + 2 < nl) l2.ext(a, esign_lo, esign_hi, nullptr); }
+        if constexpr (N > 1) l1.ext(a, esign_lo, esign_hi, nullptr);
+        if constexpr (N > 2) l2.ext(a, esign_lo, esign_hi, nullptr);
     }
     // w: the wave's index within its codeword (block geometry) / its row-wave index (packed geometry)
     __device__ __forceinline__ void twins(char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t RA, uint32_t RB, int w, int nl) const {
         dispatch_w<0, (z64_packed(ZC) ? z64p_rw(BG, ZC) : z64_nwv(ZC))>(w, [&](auto wc) {
             constexpr int WV = decltype(wc)::value;
             l0.template twins<WV>(lds, R, RA, RB, nl);
-            if constexpr (N > 1) { if (!CUT || GS + 1 < nl) l1.template twins<WV>(lds, R, RA, RB, nl); }
-            if constexpr (N > 2) { if (!CUT || GS + 2 < nl) l2.template twins<WV>(lds, R, RA, RB, nl); }
+            if constexpr (N > 1) l1.template twins<WV>(lds, R, RA, RB, nl);
+            if constexpr (N > 2) l2.template twins<WV>(lds, R, RA, RB, nl);
         });
     }
 };
@@ -727,34 +721,33 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
     }
 #else
     __builtin_amdgcn_s_setprio(NRLDPC_Z64_PRIO); // urgent until this group's writes are out (see NRLDPC_Z64_PRIO)
-    const int nlc = RT ? launder(a.n_layers) : GroupZ64<BG, ZC, GI, NL>::NO_CUT; // (read by groups the layer count may cut)
-    cur.template loads<true>(lds, R, nlc);
+    cur.template loads<true>(lds, R);
     if constexpr (GI + 1 < NG) {
         GroupZ64<BG, ZC, GI + 1, NL> nxt;
-        nxt.template loads<false>(lds, R, nlc); // columns untouched by group GI: safe before its writes
-        cur.template track<true, XF>(st, cap, nlc);
-        cur.finish(st, lds, R, a, nlc);
+        nxt.template loads<false>(lds, R); // columns untouched by group GI: safe before its writes
+        cur.template track<true, XF>(st, cap);
+        cur.finish(st, lds, R, a);
         cur.twins(lds, R, RA, RB, w, launder(a.n_layers));
         __builtin_amdgcn_s_setprio(0); // the next group's early part only fills gaps
         if constexpr (ET) {
-            cur.ext(a, esign_lo, esign_hi, nlc);
+            cur.ext(a, esign_lo, esign_hi);
             // pin the bits here: their only reader is the parity pass, and LLVM otherwise sinks all 42 rows'
             // sign computations (with lam, m1, M1, M2 of every row kept alive in scratch) down to it
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
         }
-        nxt.template track<false, XF>(st, cap, nlc);
+        nxt.template track<false, XF>(st, cap);
         // (run-time layer count: when layer GI was the last active one, the early part above was speculative -- reads of valid
         // LDS words into registers nobody uses -- and the iteration ends here)
         if (!RT || LG::group_first(GI + 1) < launder(a.n_layers))
             pipeline_z64<BG, ZC, GI + 1, ET, NL, XF>(nxt, next0, st, lds, R, RA, RB, w, a, cap, esign_lo, esign_hi);
     } else {
         if constexpr (!RT) next0.template loads<false>(lds, R);
-        cur.template track<true, XF>(st, cap, nlc);
-        cur.finish(st, lds, R, a, nlc);
+        cur.template track<true, XF>(st, cap);
+        cur.finish(st, lds, R, a);
         cur.twins(lds, R, RA, RB, w, launder(a.n_layers));
         __builtin_amdgcn_s_setprio(0); // the next group's early part only fills gaps
         if constexpr (ET) {
-            cur.ext(a, esign_lo, esign_hi, nlc);
+            cur.ext(a, esign_lo, esign_hi);
             asm volatile("" : "+v"(esign_lo), "+v"(esign_hi));
         }
         if constexpr (!RT) next0.template track<false, XF>(st, cap);
@@ -1017,18 +1010,12 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             bool stop = false; // wave-uniform
             if constexpr (FULL) { // the active rows are a compile-time fact: cheapest rows first (Own::parity_order)
                 constexpr auto PO = Own<BG, NL, -1>::parity_order();
-                int nact = 0; // run-time layer count: rows checked so far (vote points count ACTIVE rows)
                 static_for<PO.n>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int L = PO.v[i];
                     if (!stop && (!RT || L < launder(a.n_layers))) {
                         bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
-                        if constexpr (RT) {
-                            if (nact < 3 || (nact & 3) == 3) stop = __any((int)bad) != 0;
-                            ++nact;
-                        } else if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n) {
-                            stop = __any((int)bad) != 0;
-                        }
+                        if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n) stop = __any((int)bad) != 0;
                     }
                 });
             } else {

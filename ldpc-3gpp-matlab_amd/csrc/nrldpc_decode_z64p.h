@@ -189,19 +189,12 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform: every lane's codeword is settled (violated, or out of the vote)
                 constexpr auto PO = O::parity_order(); // cheapest rows first
-                int nact = 0; // run-time layer count: rows checked so far (vote points count ACTIVE rows)
                 static_for<PO.n>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int L = PO.v[i];
                     if (!stop && (!G::RT || L < launder(a.n_layers))) {
                         bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
-                        constexpr bool dense = O::ncore(L) > 10 || (i + 1 < PO.n && O::ncore(PO.v[i + 1 < PO.n ? i + 1 : i]) > 10);
-                        bool vote = i < 3 || (i % 4) == 3 || i + 1 == PO.n || dense;
-                        if constexpr (G::RT) {
-                            vote = dense || nact < 3 || (nact & 3) == 3;
-                            ++nact;
-                        }
-                        if (vote) {
+                        if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n || O::ncore(L) > 10 || (i + 1 < PO.n && O::ncore(PO.v[i + 1 < PO.n ? i + 1 : i]) > 10)) {
                             if (bad && !done) flags[c] = 1;
                             stop = __all((int)(bad | (uint32_t)done | (uint32_t)__atomic_load_n(&flags[c], __ATOMIC_RELAXED))) != 0;
                         }

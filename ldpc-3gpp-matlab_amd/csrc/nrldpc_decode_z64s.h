@@ -383,7 +383,6 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform
                 constexpr auto PO = O::parity_order(); // cheapest rows first
-                int nact = 0; // run-time layer count: rows checked so far (the cheapest rows of the table are its highest ones: pruned first)
                 static_for<PO.n>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int L = PO.v[i];
@@ -391,13 +390,8 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
                         bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
                         // (a vote right after every dense row as well: a vote is a point the compiler cannot move loads across,
                         // and 19 + 16 a-posteriori words in flight spill at 80 VGPRs)
-                        constexpr bool dense = O::ncore(L) > 10 || (i + 1 < PO.n && O::ncore(PO.v[i + 1 < PO.n ? i + 1 : i]) > 10);
-                        if constexpr (G::RT) { // the vote points count ACTIVE rows: after each of the first three, then every fourth
-                            if (dense || nact < 3 || (nact & 3) == 3) stop = __any((int)bad) != 0;
-                            ++nact;
-                        } else if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n || dense) {
+                        if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n || O::ncore(L) > 10 || (i + 1 < PO.n && O::ncore(PO.v[i + 1 < PO.n ? i + 1 : i]) > 10))
                             stop = __any((int)bad) != 0;
-                        }
                     }
                 });
                 if (bad) flags[0] = 1;

@@ -43,7 +43,7 @@ def test_headline_batch_every_codeword_against_the_oracle(pkg, orc):
     bg, Z, B, K = 1, 384, 4096, 22 * 384
     enc = pkg.Codec(bg, Z, max_iter=1, llr_dtype=np.float16)
     info = rng.integers(0, 2, (B, K), dtype=np.uint8)
-    llr = awgn_llr(rng, enc.encode(info), -0.9, np.float16, Z, E=25344)  # in the waterfall: converged and unconverged codewords
+    llr = awgn_llr(rng, enc.encode(info), -1.3, np.float16, Z, E=25344)  # in the waterfall: converged and unconverged codewords
     enc.close()
     d_llr = torch.from_numpy(llr).cuda()
     d_hard = torch.empty((B, K), dtype=torch.uint8, device="cuda")
@@ -63,7 +63,7 @@ def test_headline_batch_every_codeword_against_the_oracle(pkg, orc):
         ho, io = orc.decode_nmsq(bg, Z, llr.astype(np.float64), 25, early_term=et, **rule_kw(c))
         assert (d_hard.cpu().numpy() == ho).all(), "hard decisions differ (early_term=%s)" % et
         assert (d_it.cpu().numpy() == io).all(), "iteration counts differ (early_term=%s)" % et
-        assert 0.0 < (ho != info).any(1).mean() < 0.9  # the batch straddles the waterfall
+        assert 0.0 < (ho != info).any(1).mean() < 0.9, (ho != info).any(1).mean()  # the batch straddles the waterfall
 
 
 def test_cfg3_bg2_z384_rate_sweep_batch4096(pkg, orc):
