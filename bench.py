@@ -106,16 +106,28 @@ def bler_match():
         if os.path.exists(p):
             try:
                 d = json.load(open(p))
-                head = next(v for k, v in d.items() if "headline" in k)
+                head = next(v for k, v in d.items() if "headline" in k and "gap_dB" in v)
                 out = {"parity": "unpinned (closed-source reference decoder; compared with a restatement of its documented algorithm)",
                        "headline_gap_dB": head["gap_dB"], "EsN0_at_bler_0.1_gpu": head["EsN0_at_bler_0.1_gpu"],
                        "EsN0_at_bler_0.1_sum_product": head["EsN0_at_bler_0.1_sum_product"], "blocks": head["blocks"],
-                       "worst_gap_dB_all_configs": max(v["gap_dB"] for v in d.values()), "bound_dB": head["bound_dB"],
+                       "worst_gap_dB_all_configs": max(v["gap_dB"] for k, v in d.items() if k.startswith("cfg") and v.get("gap_dB") is not None),
+                       "bound_dB": head["bound_dB"],
                        "source": "profiles/%s_bler_gap.json (tests/test_bler_gap_gpu.py)" % tag}
                 for k in ("gap_dB_at_bler_0.01", "bound_dB_at_bler_0.01", "blocks_at_bler_0.01",
                           "gap_dB_vs_50_sum_product_sweeps_at_bler_0.01"):
                     if k in head:
                         out["headline_" + k] = head[k]
+                # round 4: the reference's own operating points (tests/test_bler_gap_gpu.py, same file)
+                at = {}
+                for k, v in d.items():
+                    if k.endswith("50it") and v.get("gap_dB_at_bler_0.01") is not None:  # 50 iterations against 50 sweeps (NRLDPCDecoder.m:41)
+                        at["50_vs_50_iterations: " + k] = {"gap_dB_at_bler_0.01": v["gap_dB_at_bler_0.01"], "bound_dB": v.get("bound_dB")}
+                    if k.startswith("demo") and v.get("gap_dB") is not None:  # plot_BLER_vs_SNR.m:29-41 through the harness, 8 vs 8
+                        at[k] = {"gap_dB_at_bler_0.1": v["gap_dB"], "bound_dB": v.get("bound_dB")}
+                    if "grid_cost" in v:
+                        at["cost_of_the_8_bit_grid: " + k] = {"dB_at_bler_0.01": v["grid_cost"].get("cost_dB_of_the_8_bit_grid_at_bler_0.01")}
+                if at:
+                    out["at_the_reference_settings"] = at
                 return out
             except Exception:
                 pass

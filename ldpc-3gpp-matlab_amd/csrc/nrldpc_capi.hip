@@ -890,13 +890,27 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             char* d_in = h->s_llr.p + off * eb;
             int kind = -1; // the handle's own format
             const double tq0 = now();
-            if (i8 && !h->pool->quantise(reinterpret_cast<int8_t*>(h->pin_in[sl].p), static_cast<const char*>(llr) + off * host_eb,
-                                         (size_t)n * ncw, hq_kind, (float)h->scale)) {
-                kind = NRLDPC_K_F16; // whatever the handle's format: this chunk reaches the decoder as fp16
+            // The first chunk is the one stretch of a call in which the device has nothing to do: it is quantised and sent in four
+            // pieces, so that its H2D copy overlaps its own quantisation (later chunks overlap the previous chunk's kernel anyway).
+            bool as_i8 = i8;
+            if (i8) {
                 int8_t* d_q = h->s_q.p + q_slot * sl;
-                HIP_TRY(hipMemcpyAsync(d_q, h->pin_in[sl].p, (size_t)n * ncw, hipMemcpyHostToDevice, h->xs[st]));
-                HIP_TRY(nrldpc::launch_expand_i8(d_q, d_in, (size_t)n * ncw, 1.0f / (float)h->scale, h->xs[st]));
-            } else { // (a chunk that holds a -inf has no int8 form)
+                int8_t* pin = reinterpret_cast<int8_t*>(h->pin_in[sl].p);
+                const size_t total = (size_t)n * ncw;
+                const int parts = (k == 0 && total >= ((size_t)1 << 20)) ? 4 : 1;
+                for (int pi = 0; pi < parts && as_i8; ++pi) {
+                    const size_t lo = (total * pi / parts) & ~(size_t)63, hi = pi + 1 == parts ? total : ((total * (pi + 1) / parts) & ~(size_t)63);
+                    if (h->pool->quantise(pin + lo, static_cast<const char*>(llr) + (off + lo) * host_eb, hi - lo, hq_kind, (float)h->scale))
+                        as_i8 = false; // a -inf: int8 has no code for it (pieces already sent are simply not used)
+                    else
+                        HIP_TRY(hipMemcpyAsync(d_q + lo, pin + lo, hi - lo, hipMemcpyHostToDevice, h->xs[st]));
+                }
+                if (as_i8) {
+                    kind = NRLDPC_K_F16; // whatever the handle's format: this chunk reaches the decoder as fp16
+                    HIP_TRY(nrldpc::launch_expand_i8(d_q, d_in, total, 1.0f / (float)h->scale, h->xs[st]));
+                }
+            }
+            if (!as_i8) { // the handle's own format (NRLDPC_HOST_I8=0, or a chunk that holds a -inf)
                 if (f64) h->pool->move(h->pin_in[sl].p, static_cast<const double*>(llr) + off, (size_t)n * ncw, true);
                 else h->pool->move(h->pin_in[sl].p, static_cast<const char*>(llr) + off * eb, (size_t)n * ncw * eb, false);
                 HIP_TRY(hipMemcpyAsync(d_in, h->pin_in[sl].p, (size_t)n * ncw * eb, hipMemcpyHostToDevice, h->xs[st]));
