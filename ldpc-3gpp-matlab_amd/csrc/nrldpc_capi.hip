@@ -660,6 +660,7 @@ int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t
     if (batch == 0) return NRLDPC_OK;
     if (!d_llr || !d_hard) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
     if (h->cfg.llr_dtype == NRLDPC_LLR_F64) return fail(NRLDPC_ERR_ARG, "f64 LLRs are accepted by the host entry point only");
+    if (d_app_out && h->cfg.early_term == 2) return fail(NRLDPC_ERR_UNSUPPORTED, "soft output is not available with the CRC-aided stop (early_term = 2)");
     DEVICE_SCOPE(h);
     return decode_launch(h, d_llr, batch, d_hard, d_iters_out, d_app_out, static_cast<hipStream_t>(stream));
 }
@@ -699,7 +700,8 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
         if (batch[i] == 0) continue;
         nrldpc_codec* h = hs[i];
         const nrldpc::Schedule& s = h->sched;
-        if ((long)batch[i] * s.Z >= env_rows && nrldpc::has_z64_kernel(s.g.bg, s.Z)) { routed.push_back(i); continue; }
+        // (a handle with the CRC-aided stop always gets a launch of its own: the shared kernel is built without it)
+        if (h->cfg.early_term == 2 || ((long)batch[i] * s.Z >= env_rows && nrldpc::has_z64_kernel(s.g.bg, s.Z))) { routed.push_back(i); continue; }
         Group& q = g[s.g.bg - 1][h->cfg.llr_dtype == NRLDPC_LLR_F16 ? 1 : 0];
         q.args.push_back(make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr));
         q.start.push_back(q.grid);
@@ -793,6 +795,7 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
     if (batch == 0) return NRLDPC_OK;
     if (!llr || !hard) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
+    if (app_out && h->cfg.early_term == 2) return fail(NRLDPC_ERR_UNSUPPORTED, "soft output is not available with the CRC-aided stop (early_term = 2)");
     DEVICE_SCOPE(h);
     const nrldpc::Schedule& s = h->sched;
     const size_t ncw = (size_t)s.g.ncols * s.Z, K = (size_t)s.g.kb * s.Z;

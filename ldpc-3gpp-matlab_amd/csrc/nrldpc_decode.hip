@@ -124,7 +124,9 @@ __device__ __forceinline__ uint32_t row_parity(char* lds, uint32_t zb, const Dec
 }
 
 // The whole decode of workgroup `blk` of one (BG, Z) configuration.
-template <int BG, int DT>
+// CRC: the CRC-aided stop compiled in (nrldpc_cfg.early_term = 2) -- builds of their own: as a run-time option it cost the other
+// calls of this kernel registers (21 -> 75 spilled on BG1) and the mixed-batch launch 10-17 %
+template <int BG, int DT, bool CRC = false>
 __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __restrict__ rot_tab, int blk) {
     using G = BGD<BG>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -210,10 +212,10 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
             if (tid <= a.ncw) flags[tid] = 0; // flags[ncw] = "some codeword of this workgroup still fails"
             // CRC-aided stop (early_term = 2): per codeword CRC_SLOTS words behind the flags (16-byte aligned)
             int* crc_slots = flags + ((a.ncw + 1 + 3) & ~3) + cwl * CRC_SLOTS;
-            if (a.crc_bits)
+            if constexpr (CRC)
                 for (int i = tid; i < a.ncw * CRC_SLOTS; i += (int)blockDim.x) flags[((a.ncw + 1 + 3) & ~3) + i] = 0;
             __syncthreads();
-            if (!done && a.crc_bits) { // every thread folds the information bits at its own ring position z of each column
+            if (CRC && !done) { // every thread folds the information bits at its own ring position z of each column
                 CrcFold f;
                 static_for<G::KB>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
@@ -241,7 +243,7 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
                 if (bad) { flags[cwl] = 1; flags[a.ncw] = 1; }
             }
             __syncthreads();
-            if (a.crc_bits) {
+            if constexpr (CRC) {
                 // a codeword whose CRC holds is done although a parity check fails; the workgroup leaves when none is left
                 if (!done && flags[cwl] != 0 && crc_holds(crc_slots)) { done = true; my_iters = it; }
                 if (tid == 0) flags[a.ncw] = 0;
@@ -266,9 +268,9 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
     }
 }
 
-template <int BG, int DT>
+template <int BG, int DT, bool CRC = false>
 __global__ __launch_bounds__(768, BG == 2 ? NRLDPC_GEN_WPE_BG2 : NRLDPC_GEN_WPE_BG1) void nrldpc_decode_kernel(const DecArgs a, const int32_t* __restrict__ rot_tab) {
-    decode_body<BG, DT>(a, rot_tab, blockIdx.x);
+    decode_body<BG, DT, CRC>(a, rot_tab, blockIdx.x);
 }
 
 // Mixed-(Z) batches in ONE launch: workgroup -> (configuration, local workgroup) through a prefix table, the
@@ -320,8 +322,8 @@ hipError_t launch_decode_multi(int bg, int llr_kind, const DecArgs* d_tab, const
                : launch_multi_t<2, NRLDPC_K_F32>(d_tab, d_start, nb, grid, lds_bytes, stream);
 }
 
-template <int BG, int DT> static hipError_t launch_t(const DecArgs& a, int grid, int threads, size_t lds, hipStream_t s) {
-    auto k = nrldpc_decode_kernel<BG, DT>;
+template <int BG, int DT, bool CRC = false> static hipError_t launch_t(const DecArgs& a, int grid, int threads, size_t lds, hipStream_t s) {
+    auto k = nrldpc_decode_kernel<BG, DT, CRC>;
     static bool attr_set[64] = {}; // per device: raising the dynamic-LDS limit is a slow host call, do it once
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -399,6 +401,13 @@ hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes
 #undef NRLDPC_Z64_CASE
     const int grid = (a.batch + a.ncw - 1) / a.ncw;
     const bool f16 = a.llr_kind == NRLDPC_K_F16;
+    if (crc) {
+        if (bg == 1)
+            return f16 ? launch_t<1, NRLDPC_K_F16, true>(a, grid, threads, lds_bytes, stream)
+                       : launch_t<1, NRLDPC_K_F32, true>(a, grid, threads, lds_bytes, stream);
+        return f16 ? launch_t<2, NRLDPC_K_F16, true>(a, grid, threads, lds_bytes, stream)
+                   : launch_t<2, NRLDPC_K_F32, true>(a, grid, threads, lds_bytes, stream);
+    }
     if (bg == 1)
         return f16 ? launch_t<1, NRLDPC_K_F16>(a, grid, threads, lds_bytes, stream)
                    : launch_t<1, NRLDPC_K_F32>(a, grid, threads, lds_bytes, stream);

@@ -789,8 +789,10 @@ template <int BG, int ZC, int NCWG, int NL> constexpr bool z64_ext_float() {
 
 // NL   : the compile-time layer count of a FULL build: all rows, or one of the pruned counts of NRLDPC_Z64_NL_LIST
 //        (the rate-matching points BASELINE.json names), each with its own barrier-group table and prefetch plan.
-template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false, int NL = BGT<BG>::ROWS>
+// CRC  : ETP with the CRC-aided stop compiled in (nrldpc_cfg.early_term = 2; a twin of its own, see the split kernel)
+template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false, int NL = BGT<BG>::ROWS, bool CRC = false>
 __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>())) void nrldpc_decode_z64_kernel(const DecArgs a) {
+    static_assert(!CRC || ETP, "the CRC-aided stop is a mode of the parity-stop build");
     static_assert(!PLAIN || FULL, "PLAIN implies FULL");
     static_assert(!ETP || (FULL && !PLAIN), "ETP implies FULL and excludes PLAIN");
     static_assert(FULL || NL == BGT<BG>::ROWS, "a run-time layer count uses the all-rows tables");
@@ -991,9 +993,9 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
     auto parity_pass = [&](int it) {
         if (tid <= G::NCWG) flags[tid] = 0;
         int* crc_slots = flags + G::FLAG_BYTES / 4 + cwl * CRC_SLOTS; // CRC-aided stop (early_term = 2)
-        if (a.crc_bits && tid < G::NCWG * CRC_SLOTS) flags[G::FLAG_BYTES / 4 + tid] = 0;
+        if constexpr (CRC) { if (tid < G::NCWG * CRC_SLOTS) flags[G::FLAG_BYTES / 4 + tid] = 0; }
         __syncthreads();
-        if (!done && a.crc_bits) { // the information bits at this thread's own ring position z of every column (primary copy:
+        if (CRC && !done) { // the information bits at this thread's own ring position z of every column (primary copy:
             CrcFold f;             // a column's last writer of an iteration leaves both copies fresh)
             const char* home = lds + cwbase + G::GUARD + 4 * z;
             static_for<G::KB>([&](auto cc) {
@@ -1035,7 +1037,7 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
         // of all 80 state registers (measured: 168 VGPRs + 234 spills instead of 129 and none)
         int mine = __builtin_amdgcn_readfirstlane(flags[cwl]);
         int any = __builtin_amdgcn_readfirstlane(flags[G::NCWG]);
-        if (a.crc_bits && any != 0) {
+        if (CRC && any != 0) {
             // a codeword whose CRC holds is done although one of its parity checks fails; then "is anybody left" is asked again
             if (!done && mine != 0 && __builtin_amdgcn_readfirstlane((int)crc_holds(crc_slots))) mine = 0;
             __syncthreads();
@@ -1143,10 +1145,10 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
     }
 }
 
-template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false, int NL = BGT<BG>::ROWS>
+template <int BG, int ZC, int NCWG, bool FULL, bool PLAIN, bool ETP = false, int NL = BGT<BG>::ROWS, bool CRC = false>
 static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
     using G = Z64<BG, ZC, NCWG, NL>;
-    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL, PLAIN, ETP, NL>;
+    auto k = nrldpc_decode_z64_kernel<BG, ZC, NCWG, FULL, PLAIN, ETP, NL, CRC>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {}; // per device: raising the dynamic-LDS limit is a slow host call, do it once
@@ -1227,6 +1229,16 @@ template <int BG, int ZC, int NCWG, int NL> static hipError_t launch_z64_pruned(
 
 template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& a, hipStream_t s) {
     constexpr int ROWS = BGT<BG>::ROWS;
+    if (a.crc_bits && !a.app) { // CRC-aided stop (early_term = 2): the parity-stop twins with the CRC compiled in, all rows or a run-time prefix
+        if constexpr (z64_has_split<BG, ZC, ROWS>()) {
+            if (use_split<BG, ZC, ROWS>())
+                return a.n_layers == ROWS ? launch_z64s<BG, ZC, true, ROWS, true>(a, s) : launch_z64s<BG, ZC, true, NL_RT, true>(a, s);
+        }
+        if constexpr (z64_has_row<BG, ZC, ROWS>()) {
+            return a.n_layers == ROWS ? launch_z64f<BG, ZC, z64_ncwg_et<BG, ZC>(), true, false, true, ROWS, true>(a, s)
+                                      : launch_z64f<BG, ZC, z64_ncwg_et<BG, ZC>(), true, false, true, NL_RT, true>(a, s);
+        }
+    }
     if constexpr (z64_has_split<BG, ZC, ROWS>()) {
         if (a.n_layers == ROWS && !a.app && use_split<BG, ZC, ROWS>())
             return a.early_term ? launch_z64s<BG, ZC, true>(a, s) : launch_z64s<BG, ZC, false>(a, s);

@@ -175,8 +175,11 @@ __device__ __forceinline__ void s_dense(GroupZ64<BG, ZC, GI, NL, H>& cur, GroupZ
     }
 }
 
-template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS>
+// CRC: the parity-stop build with the CRC-aided stop compiled in (nrldpc_cfg.early_term = 2, nrldpc_device.h: CrcFold) -- a twin of
+// its own: as a run-time option inside the ETP build it cost every parity-stop call 3-5 % (registers, the slot reset)
+template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS, bool CRC = false>
 __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) void nrldpc_decode_z64s_kernel(const DecArgs a) {
+    static_assert(!CRC || ETP, "the CRC-aided stop is a mode of the parity-stop build");
     using G = Z64S<BG, ZC, NL>;
     using LGN = LGof<BG, ZC, NL, 0>;
     static_assert(G::usable(), "split kernel: at most 1024 threads");
@@ -366,9 +369,9 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
                 // parity check of this half's rows (see parity_pass of the one-thread-per-row kernel)
                 if (u == 0) flags[0] = 0;
                 int* crc_slots = flags + 4; // CRC-aided stop (early_term = 2)
-                if (a.crc_bits && u < CRC_SLOTS) crc_slots[u] = 0;
+                if constexpr (CRC) { if (u < CRC_SLOTS) crc_slots[u] = 0; }
                 __syncthreads();
-                if (a.crc_bits) { // this half's columns (alternate ones), the bit at this thread's own ring position z (primary copy)
+                if constexpr (CRC) { // this half's columns (alternate ones), the bit at this thread's own ring position z (primary copy)
                     CrcFold f;
                     int tz = threadIdx.x; // derived again from the thread id: z is not kept live across the iteration for this
                     asm volatile("" : "+v"(tz));
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
                 if (bad) flags[0] = 1;
                 __syncthreads();
                 if (__builtin_amdgcn_readfirstlane(flags[0]) == 0) { my_iters = it; break; }
-                if (a.crc_bits) { // the CRC of the information bits holds although a parity check does not: done as well
+                if constexpr (CRC) { // the CRC of the information bits holds although a parity check does not: done as well
                     // (the slots are reset in the next parity pass, a whole iteration of barriers away from this read)
                     if (__builtin_amdgcn_readfirstlane((int)crc_holds(crc_slots)) != 0) { my_iters = it; break; }
                 }
@@ -440,9 +443,9 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
     }
 }
 
-template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t launch_z64s(const DecArgs& a, hipStream_t s) {
+template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS, bool CRC = false> static hipError_t launch_z64s(const DecArgs& a, hipStream_t s) {
     using G = Z64S<BG, ZC, NL>;
-    auto k = nrldpc_decode_z64s_kernel<BG, ZC, ETP, NL>;
+    auto k = nrldpc_decode_z64s_kernel<BG, ZC, ETP, NL, CRC>;
     constexpr size_t lds = G::lds_bytes();
     static bool attr_set[64] = {};
     int dev = 0;

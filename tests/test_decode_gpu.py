@@ -289,6 +289,37 @@ def test_crc_aided_stop(pkg, orc, bg, Z, nl, Kp, crc, esn0):
             assert (it < it1).any(), "no codeword stopped on its CRC before its parity checks held"
 
 
+def test_crc_aided_stop_in_a_mixed_call_and_without_soft_output(pkg, orc):
+    """A handle with early_term = 2 inside nrldpc_decode_multi_dev gets a launch of its own (the shared kernel is built without
+    the CRC fold) and gives what it gives alone; soft output together with the CRC-aided stop is refused, not silently downgraded."""
+    import torch
+    rng = np.random.default_rng(2024)
+    poly, L = CRC16
+    work = []
+    for bg, Z, Kp, crc in ((2, 36, 300, True), (1, 24, 500, False), (2, 384, 3840, True)):
+        kb = BG_DIMS[bg][2]
+        K, B = kb * Z, 9
+        info = np.zeros((B, K), np.uint8)
+        info[:, : Kp - L] = rng.integers(0, 2, (B, Kp - L), dtype=np.uint8)
+        for b in range(B):
+            r = orc.crc(poly, L, info[b, : Kp - L])
+            info[b, Kp - L: Kp] = (r >> np.arange(L - 1, -1, -1)) & 1
+        llr = awgn_llr(rng, orc.encode(bg, Z, info), 0.5 if bg == 1 else -0.8, np.float16, Z)
+        c = pkg.Codec(bg, Z, max_iter=15, early_term=True, llr_dtype=np.float16, crc=(poly, L, Kp) if crc else None)
+        ref_h, ref_i = c.decode(llr, want_iters=True)
+        work.append((c, torch.from_numpy(llr).cuda(), torch.zeros((B, K), dtype=torch.uint8, device="cuda"),
+                     torch.zeros(B, dtype=torch.int32, device="cuda"), ref_h, ref_i))
+    pkg.decode_multi_dev([w[0] for w in work], [w[1].data_ptr() for w in work], [w[1].shape[0] for w in work],
+                         [w[2].data_ptr() for w in work], [w[3].data_ptr() for w in work], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for c, _, h, it, ref_h, ref_i in work:
+        assert (h.cpu().numpy() == ref_h).all() and (it.cpu().numpy() == ref_i).all()
+    with pytest.raises(pkg.UnsupportedParameters):
+        work[0][0].decode(work[0][1].cpu().numpy(), want_app=True)
+    for w in work:
+        w[0].close()
+
+
 @pytest.mark.parametrize("bg,Z,B", [(1, 384, 700), (2, 7, 33), (1, 3, 5), (2, 96, 9000), (1, 64, 1)])
 def test_bit_packed_hard_output(pkg, orc, bg, Z, B):
     """nrldpc_decode_packed (ABI revision 4): the same decisions as nrldpc_decode, bit k of a codeword in byte k // 8 at bit
