@@ -1011,11 +1011,28 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
             uint32_t bad = 0;
             bool stop = false; // wave-uniform
             if constexpr (FULL) { // the active rows are a compile-time fact: cheapest rows first (Own::parity_order)
+                if constexpr (RT) { // run-time layer count: highest row first, pruned rows skipped eight at a time (Own::parity_order_desc)
+                    constexpr auto PD = Own<BG, NL, -1>::parity_order_desc();
+                    static_for<(PD.n + 7) / 8>([&](auto bc) {
+                        constexpr int b0 = 8 * decltype(bc)::value, b1 = b0 + 8 < PD.n ? b0 + 8 : PD.n;
+                        const int nlb = launder(a.n_layers);
+                        if (!stop && PD.v[b1 - 1] < nlb) {
+                            static_for<b1 - b0>([&](auto ic) {
+                                constexpr int i = b0 + decltype(ic)::value;
+                                constexpr int L = PD.v[i];
+                                if (!stop && L < nlb) {
+                                    bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                                    if constexpr ((i % 4) == 3 || i + 1 == b1 || L < 4) stop = __any((int)bad) != 0;
+                                }
+                            });
+                        }
+                    });
+                }
                 constexpr auto PO = Own<BG, NL, -1>::parity_order();
-                static_for<PO.n>([&](auto ic) {
+                if constexpr (!RT) static_for<PO.n>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int L = PO.v[i];
-                    if (!stop && (!RT || L < launder(a.n_layers))) {
+                    if (!stop) {
                         bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
                         if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n) stop = __any((int)bad) != 0;
                     }

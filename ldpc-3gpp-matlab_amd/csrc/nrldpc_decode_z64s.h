@@ -385,8 +385,27 @@ __global__ __launch_bounds__(2 * z64_nwv(ZC) * 64, (Z64S<BG, ZC, NL>::wpe())) vo
                 }
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform
+                if constexpr (G::RT) {
+                    // run-time layer count: highest row first, pruned rows skipped eight at a time (Own::parity_order_desc)
+                    constexpr auto PD = O::parity_order_desc();
+                    static_for<(PD.n + 7) / 8>([&](auto bc) {
+                        constexpr int b0 = 8 * decltype(bc)::value, b1 = b0 + 8 < PD.n ? b0 + 8 : PD.n;
+                        const int nlb = launder(a.n_layers);
+                        if (!stop && PD.v[b1 - 1] < nlb) { // the block's lowest row is active: the block has work
+                            static_for<b1 - b0>([&](auto ic) {
+                                constexpr int i = b0 + decltype(ic)::value;
+                                constexpr int L = PD.v[i];
+                                if (!stop && L < nlb) {
+                                    bad |= row_parity_z64<BG, ZC, L>(lds, R, esign_lo, esign_hi);
+                                    if constexpr ((i % 4) == 3 || i + 1 == b1 || O::ncore(L) > 10 || (i + 1 < PD.n && O::ncore(PD.v[i + 1 < PD.n ? i + 1 : i]) > 10))
+                                        stop = __any((int)bad) != 0;
+                                }
+                            });
+                        }
+                    });
+                }
                 constexpr auto PO = O::parity_order(); // cheapest rows first
-                static_for<PO.n>([&](auto ic) {
+                if constexpr (!G::RT) static_for<PO.n>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int L = PO.v[i];
                     if (!stop && (!G::RT || L < launder(a.n_layers))) {

@@ -152,6 +152,17 @@ template <int BG, int NL_, int H, int V = 0> struct Own {
         }
         return o;
     }
+    // ... and highest row first: the parity-pass order of the builds with a run-time layer count.  The rows a layer count prunes
+    // are then the FIRST ones of the list, in whole blocks that one scalar branch skips (a taken branch per pruned row was a
+    // third of those builds' distance to the compile-time ones under the parity stop), and what is left runs cheap rows (the
+    // high, sparse ones) before the dense core rows all the same.
+    static constexpr Order parity_order_desc() {
+        Order o{};
+        o.n = 0;
+        for (int l = NL - 1; l >= 0; --l)
+            if (mine(l)) o.v[o.n++] = l;
+        return o;
+    }
     static constexpr int NCORE = H < 0 ? G::NCORE : core_base(NL);
     static constexpr int NEXT = H < 0 ? G::NEXT : ext_index(NL);
     static constexpr int NW = (NCORE + 3) / 4, NXW = (NEXT + 3) / 4;

@@ -1,17 +1,17 @@
 #!/bin/bash
 # rocprofv3 kernel trace + two PMC passes of ONE (BG, Z) decoder configuration (tools/bench_one.py), on the GPU box:
-#   tools/profile_one.sh <bg> <Z> [n_layers]  -> gpurun_out/prof_one_<bg>_<Z>[_nl<n>]/{stats,sqA,sqB}/...  and a summary line per kernel
+#   tools/profile_one.sh <bg> <Z> [n_layers [early_term]]  -> gpurun_out/prof_one_<bg>_<Z>[_nl<n>]/{stats,sqA,sqB}/...  and a summary line per kernel
 # (a layer count profiles the pruned call; NRLDPC_NO_PRUNED_PIPELINE=1 in the environment sends it to the run-time-prefix build)
 # (separate runs with --kernel-trace only, never combined with sys/hip traces)
 set -u
-BG=$1; Z=$2; NL=${3:-0}
+BG=$1; Z=$2; NL=${3:-0}; ET=${4:-0}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-TAGN=${BG}_${Z}$([ "$NL" != "0" ] && echo _nl$NL)
+TAGN=${BG}_${Z}$([ "$NL" != "0" ] && echo _nl$NL)$([ "$ET" != "0" ] && echo _et)${TAGX:-}
 OUT=$ROOT/gpurun_out/prof_one_${TAGN}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=$(python -c "print(max(4096, (4096 * 384 // $Z) // 256 * 256))")
-CMD="python $ROOT/tools/bench_one.py $BG $Z $B 0 $NL"
+CMD="python $ROOT/tools/bench_one.py $BG $Z $B $ET $NL"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $OUT/sqA -o sqA -- $CMD > $OUT/sqA.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/sqB -o sqB -- $CMD > $OUT/sqB.log 2>&1
