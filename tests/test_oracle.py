@@ -214,3 +214,56 @@ def test_golden_fixture(orc):
         assert (app.astype(np.float16) == g[name + "/app_f16"]).all()
         cw = orc.encode(int(bg), int(Z), g[name + "/info"])
         assert (np.packbits(cw, axis=1) == g[name + "/cw_packed"]).all()
+
+
+@pytest.mark.parametrize("bg,Z,nl,Kp,poly,L,esn0", [(2, 20, 12, 116, 0x11021, 16, 1.6), (1, 24, 0, 400, 0x1800063, 24, -0.3), (2, 36, 22, 360, 0x1864CFB, 24, -0.9)])
+def test_crc_aided_stop_variant_of_the_oracle(orc, bg, Z, nl, Kp, poly, L, esn0):
+    """orc_decode_onmsq_crc (the checker of nrldpc_cfg.early_term = 2) pinned against its own definition, built from pieces that
+    are pinned elsewhere: run the fixed-iteration decoder for 1, 2, 3, ... iterations; the CRC-aided stop must end at the first
+    count whose hard decisions satisfy every active parity check OR leave CRC remainder 0 on the first K' bits with a bit set
+    (bit-serial CRC: orc_crc, itself pinned against the chain's literal loops), with exactly those hard decisions."""
+    rng = np.random.default_rng(31 * Z + Kp)
+    rows, cols, kb = BG_DIMS[bg]
+    K, B, cap = kb * Z, 10, 12
+    nla = nl or rows
+    info = np.zeros((B, K), np.uint8)
+    info[:, : Kp - L] = rng.integers(0, 2, (B, Kp - L), dtype=np.uint8)
+    for b in range(B):
+        r = orc.crc(poly, L, info[b, : Kp - L])
+        info[b, Kp - L: Kp] = (r >> np.arange(L - 1, -1, -1)) & 1
+    cw = orc.encode(bg, Z, info)
+    llr = awgn_llr(rng, cw, esn0, np.float32, Z).astype(np.float64)
+    llr[:, Kp:K] = np.inf
+    llr[3, : 4 * Z] = 0  # punctured systematic bits: all-zero decisions early on must not count as a CRC match
+    hard, iters = orc.decode_nmsq_crc(bg, Z, llr, cap, (poly, L, Kp), n_layers=nl, alpha=0.875, beta=2.0)
+    _, it_parity = orc.decode_nmsq(bg, Z, llr, cap, n_layers=nl, early_term=True, alpha=0.875, beta=2.0)
+    assert (iters <= it_parity).all()
+    stopped_by_crc = 0
+    for b in range(B):
+        want = None
+        for it in range(1, cap + 1):
+            h, _, app = orc.decode_nmsq(bg, Z, llr[b:b + 1], it, n_layers=nl, early_term=False, alpha=0.875, beta=2.0, want_app=True)
+            word = (app[0] < 0).astype(np.uint8)
+            parity_ok = orc.syndrome_weight(bg, Z, word, n_layers=nla) == 0
+            crc_ok = orc.crc(poly, L, h[0, :Kp]) == 0 and h[0, :Kp].any()
+            if parity_ok or crc_ok or it == cap:
+                want = (it, h[0])
+                stopped_by_crc += int(crc_ok and not parity_ok)
+                break
+        assert iters[b] == want[0] and (hard[b] == want[1]).all(), b
+    assert stopped_by_crc > 0  # the case exercises the CRC branch, not only the parity one
+
+
+def test_wide_grid_variant_equals_the_build_algorithm_at_127(orc):
+    """orc_decode_onmsq_wide with the kernels' own saturation (+-127) IS orc_decode_onmsq; with a wider grid it differs only
+    where a value saturated."""
+    rng = np.random.default_rng(8)
+    bg, Z = 1, 16
+    info = rng.integers(0, 2, (6, 22 * Z), dtype=np.uint8)
+    llr = awgn_llr(rng, orc.encode(bg, Z, info), 1.0, np.float32, Z).astype(np.float64)
+    llr[0] *= 40.0  # this block saturates the 8-bit grid
+    a = orc.decode_nmsq(bg, Z, llr, 8, early_term=True, alpha=0.875, beta=3.0)
+    b = orc.decode_nmsq_wide(bg, Z, llr, 8, early_term=True, alpha=0.875, beta=3.0, qmax=127)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    c = orc.decode_nmsq_wide(bg, Z, llr, 8, early_term=True, alpha=0.875, beta=3.0, qmax=32767)
+    assert (c[0][1:] == a[0][1:]).all() and (c[1][1:] == a[1][1:]).all()
