@@ -366,6 +366,16 @@ hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes
     static const bool no_packed = getenv("NRLDPC_NO_PACKED") != nullptr;
     // (the CRC-aided stop, early_term = 2, lives in the block-geometry and run-time-Z kernels: packed sizes take those then)
     const bool crc = a.crc_bits != 0;
+    // the interleaved block geometry: hard output, any layer count -- for what each entry's mode lists (1 fixed iteration counts,
+    // 2 parity stop with every row active, 4 parity stop with pruned rows: measured per size, profiles/r04_ilv_ab.txt).
+    // NRLDPC_NO_ILV=1: A/B against the kernels that served these sizes before
+    static const bool no_ilv = getenv("NRLDPC_NO_ILV") != nullptr;
+    if (!force_generic && !no_ilv && !a.app && !crc) {
+        const int want = !a.early_term ? 1 : a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) ? 2 : 4;
+#define NRLDPC_Z64I_CASE(b, z, ncw, mode) if (bg == b && a.Z == z && ((mode) & want)) return launch_decode_z64i_##b##_##z(a, stream);
+        NRLDPC_Z64I_LIST(NRLDPC_Z64I_CASE)
+#undef NRLDPC_Z64I_CASE
+    }
     if (!force_generic && !no_packed && !a.app && !crc) { // pruned layer counts with packed builds of their own
 #define NRLDPC_Z64P_NL_CASE(b, z, nl) if (bg == b && a.Z == z && a.n_layers == nl) return launch_decode_z64p_##b##_##z##_nl##nl(a, stream);
         NRLDPC_Z64P_NL_LIST(NRLDPC_Z64P_NL_CASE)

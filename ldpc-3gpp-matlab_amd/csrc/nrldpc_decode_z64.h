@@ -86,6 +86,20 @@ constexpr bool z64_packed(int) {
     return false;
 #endif
 }
+// "Interleaved" block geometry (round 4; nrldpc_decode_z64p.h runs it): NCW whole codewords of a SMALL lifting size Zr share one
+// workgroup of the BLOCK geometry of the virtual size ZC = Zr * NCW -- row lane g = z * NCW + c as in the packed geometry, but the
+// ring of a column is the block geometry's [guard][ZC words][64-word mirror of block 0]: a base-graph shift P of the real code is
+// the shift P * NCW of the virtual one, a compile-time constant like any other, so base registers per ring block, immediates,
+// the twin analysis (one extra store per edge in one or two waves instead of a masked one in every wave), LDS size (no doubled
+// rings) are those of Z = 256 / 384 / 240 ...: the shapes that run fastest.  -DNRLDPC_Z64_ILV=<NCW> with -DNRLDPC_Z64_Z=<ZC>.
+constexpr int z64_ilv() {
+#ifdef NRLDPC_Z64_ILV
+    return NRLDPC_Z64_ILV;
+#else
+    return 1;
+#endif
+}
+
 // Row waves per half of a packed workgroup: 1, 2 or 4 -- the first of these that fills 80 % of its lanes, else the best filled.
 // Measured (one session each, fixed 25 / parity stop): for Z <= 32 two-wave halves gain 2-10 % at fixed iterations where they
 // fill more lanes but lose 10-25 % with the parity stop on BG1 (a workgroup lives until its last codeword converges, and
@@ -93,11 +107,13 @@ constexpr bool z64_packed(int) {
 // + 1 + 1 waves on the four SIMDs) lose 14-48 % everywhere; four-wave halves are fine (Z = 72, 80); five and more (BG2 Z = 52
 // ... 352 with 6-8 codewords or 10-16 waves per workgroup) lose to the block geometry.  BG1's last column would also lie
 // beyond the 64 KB an LDS instruction's immediate offset reaches with more than 4.
+constexpr int z64_blk(int Z);
 constexpr int z64p_rw(int BG, int Z) {
 #ifdef NRLDPC_Z64P_RW
     return NRLDPC_Z64P_RW;
 #endif
     (void)BG;
+    if (z64_ilv() > 1) return Z / z64_blk(Z); // interleaved block geometry: the virtual size's waves per codeword
     // Large lifting sizes of BG1 that do not split into full waves in the block geometry (11 or 3 times a power of two: blocks of
     // 44-48 rows leave 25-31 % of the lanes idle): 6-wave halves -- the 12-wave workgroup shape of Z = 384's split kernel -- carry
     // 352 rows (4 x 88, 2 x 176, 1 x 352) or 384 (4 x 96).  Measured against the kernels these sizes ran before, one session
@@ -114,7 +130,7 @@ constexpr int z64p_rw(int BG, int Z) {
     }
     return best;
 }
-constexpr int z64p_ncw(int BG, int Z) { return 64 * z64p_rw(BG, Z) / Z; } // codewords per packed workgroup
+constexpr int z64p_ncw(int BG, int Z) { return z64_ilv() > 1 ? z64_ilv() : 64 * z64p_rw(BG, Z) / Z; } // codewords per packed workgroup
 
 // Rows per wave ("block"): 64 when 64 | Z, else the largest divisor of Z below 64 that is a multiple of 4.
 // A wave then owns B consecutive rows and its lanes B..63 retire at kernel entry (Z = 240 -> 4 waves of 60
@@ -123,6 +139,10 @@ constexpr int z64p_ncw(int BG, int Z) { return 64 * z64p_rw(BG, Z) / Z; } // cod
 constexpr int z64_blk(int Z) {
     if (z64_packed(Z)) return Z; // the whole ring: every shift is an offset from one base address
     if (Z % 64 == 0) return 64;
+    if (z64_ilv() > 1) { // interleaved units read and write single words only: any divisor will do (252 = 4 x 63, 220 = 4 x 55)
+        for (int b = 63; b >= 4; --b)
+            if (Z % b == 0) return b;
+    }
     for (int b = 60; b >= 4; b -= 4)
         if (Z % b == 0) return b;
     return 0;
@@ -213,8 +233,11 @@ template <int BG, int ZC, int NCWG_ = z64_ncwg<BG, ZC>(), int NL_ = BGT<BG>::ROW
     static constexpr int pb(int c, int P) { return PACKED ? (c >= HICOL ? 1 : 0) : ridx(P); }
     static constexpr int po(int c, int P) { return c * CS + roff(P) + (PACKED ? GUARD - (c >= HICOL ? HIOFF : 0) : 0); }
     static constexpr int NCWG = NCWG_;                  // codewords per workgroup
-    static constexpr int ILS = z64_set_index(ZC);
-    static constexpr int shift(int e) { return (BG == 1 ? nr_bg1_shift[ILS][e] : nr_bg2_shift[ILS][e < NR_BG2_NNZ ? e : 0]) % ZC; }
+    static constexpr int ILV = z64_ilv();               // interleaved block geometry: codewords of the real size ZR per workgroup
+    static constexpr int ZR = ZC / ILV;                 // the lifting size of the code (= ZC unless interleaved)
+    static_assert(ZC % ILV == 0 && z64_set_index(ZR) >= 0, "the virtual size is a multiple of a real lifting size");
+    static constexpr int ILS = z64_set_index(ZR);
+    static constexpr int shift(int e) { return ((BG == 1 ? nr_bg1_shift[ILS][e] : nr_bg2_shift[ILS][e < NR_BG2_NNZ ? e : 0]) % ZR) * ILV; }
     // Mirror coherence analysis (all layers active).  After edge e rewrites its column, ring words i >= kb_e
     // are fresh in the primary copy of block 0 and words i < kb_e are fresh in the mirror.  The next edge on
     // the same column (cyclic layer order) reads words i >= kb' from the primary copy and words i < kb' from

@@ -16,15 +16,27 @@ namespace nrldpc {
 
 template <int BG, int ZC, int NL = BGT<BG>::ROWS> struct Z64P : Z64<BG, ZC, 1, NL> {
     using B = Z64<BG, ZC, 1, NL>;
-    static_assert(B::PACKED && B::NWV == 1, "packed geometry");
+    static constexpr bool ILVM = B::ILV > 1;          // interleaved BLOCK geometry (z64_ilv): ZC is the virtual size
+    static_assert(ILVM ? !B::PACKED : (B::PACKED && B::NWV == 1), "packed geometry, or the block geometry with interleaved codewords");
     static constexpr int RW = z64p_rw(BG, ZC);       // row waves per half
     static constexpr int NCW = z64p_ncw(BG, ZC);     // codewords per workgroup
-    static constexpr int NROW = ZC * NCW;        // row lanes in use (of 64 RW)
+    static constexpr int NROW = ILVM ? ZC : ZC * NCW; // row lanes in use (of 64 RW; interleaved: BLK of every wave's 64)
     static constexpr int THREADS = 2 * RW * 64;
-    static_assert(NCW >= 1 && NROW <= 64 * RW && 64 * RW - NROW < 64 && NCW + 1 <= NROW && 2 * RW <= 16, "packed workgroup shape");
-    static_assert(B::NROWP == NROW && B::po(B::NC - 1, ZC - 1) + 4 * NROW < 65536 && B::po(B::HICOL < B::NC ? B::HICOL : 0, 0) - 4 * NROW >= 0, "LDS immediate offsets");
+    static_assert(ILVM || (NCW >= 1 && NROW <= 64 * RW && 64 * RW - NROW < 64 && NCW + 1 <= NROW), "packed workgroup shape");
+    static_assert(2 * RW <= 16 && NCW + 1 <= NROW, "workgroup shape");
+    static_assert(ILVM || (B::NROWP == NROW && B::po(B::NC - 1, ZC - 1) + 4 * NROW < 65536 && B::po(B::HICOL < B::NC ? B::HICOL : 0, 0) - 4 * NROW >= 0), "LDS immediate offsets");
     static constexpr size_t FLAGS = (size_t)B::GUARD + B::CWS; // [guard][NC columns of ring | mirror][flags]
-    static constexpr size_t lds_bytes() { return FLAGS + 4 * (size_t)((NCW + 1 + 3) / 4 * 4); }
+    // Interleaved block geometry: the extension-column channel LLRs live in LDS behind the flags, one int8 per extension row and
+    // row lane ([row][lane] bytes, as in the split kernels of the block geometry: DecStateS, Z64S::XL), where that does not
+    // cost a workgroup per CU -- without them the parity-stop build spills 130 registers at 80 VGPRs
+    static constexpr size_t XOFF = FLAGS + 4 * (size_t)((NCW + 1 + 3) / 4 * 4);
+    static constexpr size_t XBYTES = (size_t)(B::NLT - 4) * ZC;
+    static constexpr int wgs_per_cu(size_t lds) {
+        const int by_waves = 24 / (2 * RW) > 0 ? 24 / (2 * RW) : 1, by_lds = (int)((160 * 1024) / lds);
+        return by_waves < by_lds ? by_waves : by_lds;
+    }
+    static constexpr bool XL = ILVM && wgs_per_cu(XOFF + XBYTES) == wgs_per_cu(XOFF);
+    static constexpr size_t lds_bytes() { return XOFF + (XL ? XBYTES : 0); }
 };
 
 // waves per SIMD the register allocation is sized for: what the LDS image lets a CU hold anyway (BG1: 4, i.e. 128 VGPRs), at most 6
@@ -37,7 +49,9 @@ template <int BG, int ZC, int NL> constexpr int z64p_wpe() {
 }
 
 // NL: the active rows 0..NL-1, a compile-time fact (all rows, or one of the pruned counts of NRLDPC_Z64P_NL_LIST)
-template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS>
+// ILVT: the unit's interleave factor, a template argument ONLY so that it is part of the kernel's name -- the units of 128 x 2,
+// 64 x 4, 32 x 8 ... all instantiate <BG, 256, ...>, a kernel handle is a weak symbol, and the linker would keep the first one's
+template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS, int ILVT = z64_ilv()>
 __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>())) void nrldpc_decode_z64p_kernel(const DecArgs a) {
     using G = Z64P<BG, ZC, NL>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -45,28 +59,41 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave / G::RW, lane = tid & 63;
     const int rw = wave % G::RW;         // row wave
-    const int g = rw * 64 + lane;         // row lane
-    if constexpr (G::NROW < 64 * G::RW) {
+    const int g = G::ILVM ? rw * G::BLK + lane : rw * 64 + lane; // row lane (interleaved: a wave owns BLK consecutive ring positions)
+    if constexpr (G::ILVM) {
+        if constexpr (G::BLK < 64) {
+            if (lane >= G::BLK) return;
+        }
+    } else if constexpr (G::NROW < 64 * G::RW) {
         if (g >= G::NROW) return; // these lanes own no row; barriers count waves, not lanes (no wave is empty: fewer than Z lanes retire, and the shape rule keeps that below 64)
     }
     const int z = g / G::NCW, c = g - z * G::NCW;
     const int cw = blockIdx.x * G::NCW + c;
     const bool present = cw < a.batch; // the last workgroup of a launch may hold fewer codewords: the others decode zeros
     int* flags = reinterpret_cast<int*>(lds + G::FLAGS);
-    constexpr size_t ncwz = (size_t)G::COLS * ZC;
+    constexpr int ZR = G::ZR;          // the code's own lifting size: what the LLR and hard-decision arrays are laid out by
+    constexpr size_t ncwz = (size_t)G::COLS * ZR;
     constexpr bool XF = false;
     constexpr int V = z64s_variant<BG, ZC, NL>();
-    static_assert((V & SPLIT_DUAL) == 0, "no dual rows in the packed geometry");
+    static_assert((V & SPLIT_DUAL) == 0, "no dual rows in this kernel (interleaved units are built with -DNRLDPC_Z64S_DUAL=0)");
 
-    // base registers of the edge addresses (Z64::pb / po): the thread's word of the guard in front of column 0 [and the same HIOFF
-    // bytes further for the columns an immediate offset from R[0] does not reach]; opaque, so that the compiler keeps them as they are
+    // base registers of the edge addresses (Z64::pb / po).  Packed geometry: the thread's word of the guard in front of column 0
+    // [and the same HIOFF bytes further for the columns an immediate offset from R[0] does not reach]; opaque, so that the compiler
+    // keeps them as they are.  Interleaved block geometry: the block geometry's own -- one base per ring block, RA / RB for the twins.
     uint32_t R[G::NBASE];
-    R[0] = 4u * (uint32_t)g;
-    if constexpr (G::NBASE > 1) {
-        R[1] = R[0] + (uint32_t)G::HIOFF;
-        asm volatile("" : "+v"(R[1]));
+    uint32_t RA = 0, RB = 0;
+    if constexpr (G::ILVM) {
+#pragma unroll
+        for (int k = 0; k < G::NBASE; ++k) R[k] = (uint32_t)G::GUARD + (uint32_t)(4 * G::BLK) * (uint32_t)((rw + k) % G::RW) + 4u * (uint32_t)lane;
+        RA = (uint32_t)(G::GUARD - 4 * G::BLK) + 4u * (uint32_t)lane;
+        RB = (uint32_t)G::GUARD + 4u * ZC + 4u * (uint32_t)lane;
+    } else {
+        R[0] = 4u * (uint32_t)g;
+        if constexpr (G::NBASE > 1) {
+            R[1] = R[0] + (uint32_t)G::HIOFF;
+            asm volatile("" : "+v"(R[1]));
+        }
     }
-    constexpr uint32_t RA = 0, RB = 0;                           // (the block geometry's twin bases: unused here)
     const uint32_t home0 = (uint32_t)G::GUARD + 4u * (uint32_t)g; // this thread's word of column 0's ring
     const size_t base = (size_t)(present ? cw : 0) * ncwz;
 
@@ -81,8 +108,8 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                 const int col = 2 * k + half;
                 x[k] = 0u;
                 if (present && (2 * k + 1 < G::NC || col < G::NC)) {
-                    if constexpr (F16) x[k] = static_cast<const uint16_t*>(a.llr)[base + (size_t)col * ZC + z];
-                    else x[k] = static_cast<const uint32_t*>(a.llr)[base + (size_t)col * ZC + z];
+                    if constexpr (F16) x[k] = static_cast<const uint16_t*>(a.llr)[base + (size_t)col * ZR + z];
+                    else x[k] = static_cast<const uint32_t*>(a.llr)[base + (size_t)col * ZR + z];
                 }
             });
             static_for<NPU>([&](auto kc) {
@@ -95,7 +122,11 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                     const float q = present ? ingest(v, a.scale, true) : 0.0f;
                     char* home = lds + home0 + col * G::CS;
                     *reinterpret_cast<float*>(home) = q;
-                    *reinterpret_cast<float*>(home + 4 * G::NROW) = q;
+                    if constexpr (G::ILVM) {
+                        if (g < G::BLK) *reinterpret_cast<float*>(home + 4 * ZC) = q; // mirror of ring block 0
+                    } else {
+                        *reinterpret_cast<float*>(home + 4 * G::NROW) = q;
+                    }
                 }
             });
         };
@@ -104,25 +135,47 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
     }
 
     // hard decisions of this thread's columns of its codeword (the halves take alternate columns) + the iteration count
+    // Where this thread sits, derived AGAIN from the thread id through an opaque copy: the parity pass and the write-back need the
+    // codeword index and the row position once per iteration at most, and values computed before the iteration loop and used
+    // only there would stay live across it -- at 80 VGPRs the compiler parks them in scratch (as in the block geometry's kernel).
+    struct Where { int half, g, z, c, cw; uint32_t home0; };
+    auto where = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        Where p;
+        const int wv = t >> 6, ln = t & 63;
+        p.half = wv / G::RW;
+        p.g = G::ILVM ? (wv % G::RW) * G::BLK + ln : (wv % G::RW) * 64 + ln;
+        p.z = p.g / G::NCW;
+        p.c = p.g - p.z * G::NCW;
+        p.cw = blockIdx.x * G::NCW + p.c;
+        p.home0 = (uint32_t)G::GUARD + 4u * (uint32_t)p.g;
+        return p;
+    };
     auto write_out = [&](int it) {
-        uint8_t* hard = a.hard + (size_t)cw * ((size_t)G::KB * ZC) + z;
+        const Where p = where();
+        uint8_t* hard = a.hard + (size_t)p.cw * ((size_t)G::KB * ZR) + p.z;
         static_for<(G::KB + 1) / 2>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            const int col = 2 * k + half;
+            const int col = 2 * k + p.half;
             if (2 * k + 1 < G::KB || col < G::KB)
-                hard[(size_t)col * ZC] = *reinterpret_cast<const float*>(lds + home0 + col * G::CS) < 0.0f ? 1 : 0;
+                hard[(size_t)col * ZR] = *reinterpret_cast<const float*>(lds + p.home0 + col * G::CS) < 0.0f ? 1 : 0;
         });
-        if (a.iters && z == 0 && half == 0) a.iters[cw] = it;
+        if (a.iters && p.z == 0 && p.half == 0) a.iters[p.cw] = it;
     };
 
     auto run = [&](auto hc) {
         constexpr int H = decltype(hc)::value;
         using O = Own<BG, NL, H, V>;
-        DecStateS<BG, NL, H, ZC, false, V> st;
+        DecStateS<BG, NL, H, ZC, G::XL, V> st;
 #pragma unroll
         for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
+        if constexpr (G::XL) { // half 0's extension rows first, then half 1's: [row][lane] bytes
+            st.xp = (lds_i8_t)(lds + G::XOFF + (size_t)(H == 0 ? 0 : Own<BG, NL, 0, V>::NEXT) * ZC + g);
+        } else {
 #pragma unroll
-        for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
+            for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
+        }
         auto load_ext = [&](auto kind_c) {
             constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
             uint32_t xe[O::NEXT > 0 ? O::NEXT : 1];
@@ -135,7 +188,7 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                     constexpr int L = L0 + decltype(ic)::value;
                     if constexpr (O::mine(L)) {
                         constexpr int xi = O::ext_index(L);
-                        const size_t i = base + (size_t)(G::NC + L - 4) * ZC + z;
+                        const size_t i = base + (size_t)(G::NC + L - 4) * ZR + z;
                         xe[xi] = 0u;
                         if (used) {
                             if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
@@ -184,8 +237,9 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
             if constexpr (ETP) {
                 // parity check of this half's rows, per codeword: flags[c] = "codeword c has a violated check",
                 // flags[NCW] = "a codeword that had not converged before still has one"
-                if (tid <= G::NCW) flags[tid] = 0;
+                if ((int)threadIdx.x <= G::NCW) flags[threadIdx.x] = 0;
                 __syncthreads();
+                const int c = where().c; // (this shadows the prologue's copy on purpose: see `where`)
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform: every lane's codeword is settled (violated, or out of the vote)
                 auto vote = [&]() {
@@ -236,7 +290,7 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
 
 template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t launch_z64p_t(const DecArgs& a, hipStream_t s) {
     using G = Z64P<BG, ZC, NL>;
-    auto k = nrldpc_decode_z64p_kernel<BG, ZC, ETP, NL>;
+    auto k = nrldpc_decode_z64p_kernel<BG, ZC, ETP, NL, z64_ilv()>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {};

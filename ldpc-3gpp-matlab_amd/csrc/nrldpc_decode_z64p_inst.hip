@@ -7,14 +7,36 @@
 #ifndef NRLDPC_Z64_Z
 #define NRLDPC_Z64_Z 32
 #endif
+#ifndef NRLDPC_Z64_ILV
 #define NRLDPC_Z64_PACK 1 // the geometry of this unit (z64_packed, nrldpc_decode_z64.h)
+#endif
+// -DNRLDPC_Z64_ILV=<NCW> -DNRLDPC_Z64_Z=<Zr * NCW> -DNRLDPC_Z64I_ZR=<Zr> -DNRLDPC_Z64S_DUAL=0: the interleaved BLOCK geometry instead
+// (z64_ilv): NCW codewords of the lifting size Zr in one workgroup of the virtual size's block geometry (NRLDPC_Z64I_LIST)
 #include "nrldpc_decode_z64p.h"
 
 #define NRLDPC_CAT_(a, b, c) a##b##_##c
 #define NRLDPC_CAT(a, b, c) NRLDPC_CAT_(a, b, c)
 
 namespace nrldpc {
-#ifdef NRLDPC_Z64P_ROW
+#ifdef NRLDPC_Z64_ILV
+#ifndef NRLDPC_Z64I_MODE
+#define NRLDPC_Z64I_MODE 7
+#endif
+// only what the list entry's mode serves is instantiated (1 fixed iteration counts, 2 parity stop with every row active, 4 parity
+// stop with pruned rows: NRLDPC_Z64I_LIST); launch_decode asks for nothing else
+hipError_t NRLDPC_CAT(launch_decode_z64i_, NRLDPC_Z64_BG, NRLDPC_Z64I_ZR)(const DecArgs& a, hipStream_t stream) {
+    constexpr int BG = NRLDPC_Z64_BG, ZC = NRLDPC_Z64_Z, MODE = NRLDPC_Z64I_MODE;
+    const bool pruned = a.n_layers != BGT<BG>::ROWS; // any other layer count: the run-time-prefix builds (NL_RT)
+    if (!a.early_term) {
+        if constexpr ((MODE & 1) != 0) return pruned ? launch_z64p_t<BG, ZC, false, NL_RT>(a, stream) : launch_z64p_t<BG, ZC, false>(a, stream);
+    } else if (!pruned) {
+        if constexpr ((MODE & 2) != 0) return launch_z64p_t<BG, ZC, true>(a, stream);
+    } else {
+        if constexpr ((MODE & 4) != 0) return launch_z64p_t<BG, ZC, true, NL_RT>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+#elif defined(NRLDPC_Z64P_ROW)
 // -DNRLDPC_Z64P_ROW=1 (with -DNRLDPC_Z64P_RW=<waves>): the pipelined one-thread-per-row builds of this (BG, Z) only (NRLDPC_Z64PR_LIST)
 hipError_t NRLDPC_CAT(launch_decode_z64pr_, NRLDPC_Z64_BG, NRLDPC_Z64_Z)(const DecArgs& a, hipStream_t stream) {
     return launch_z64pr<NRLDPC_Z64_BG, NRLDPC_Z64_Z>(a, stream);

@@ -186,8 +186,13 @@ def test_kernel_lists_of_the_build_and_of_the_dispatch_agree():
     assert sorted(pairs("NRLDPC_Z64PR_LIST")) == sorted(bld.Z64PR)
     assert sorted(pairs("NRLDPC_Z64_NL_LIST")) == sorted(bld.Z64_NL)
     assert sorted(pairs("NRLDPC_Z64P_NL_LIST")) == sorted(bld.Z64P_NL)
+    assert sorted(pairs("NRLDPC_Z64I_LIST")) == sorted(bld.Z64I)
     assert set(pairs("NRLDPC_Z64P_NOT_ET")) <= set(bld.Z64P_PAIRS)
     # a packed size that has no block-geometry unit falls back to the run-time-Z kernel for pruned rows / soft output: fine;
     # but every lifting size of TS 38.212 must be a legal Z for it
     all_z = sorted(a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384)
     assert all(z in all_z for _, z in bld.Z64_PAIRS + bld.Z64P_PAIRS + [(b, z) for b, z, _ in bld.Z64PR])
+    # interleaved block geometry: the virtual size is a block-geometry shape of full (or nearly full) waves, at most 8 per half
+    # (at most 8 waves of at most 64 rows per half, and a mode that serves something)
+    assert all(z in all_z and 2 <= n and z * n <= 512 and 1 <= m <= 7 for _, z, n, m in bld.Z64I)
+    assert len({(b, z) for b, z, _, _ in bld.Z64I}) == len(bld.Z64I)

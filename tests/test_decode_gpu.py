@@ -122,6 +122,33 @@ def test_run_time_layer_count_grid(pkg, orc, bg, Z):
 
 
 @pytest.mark.parametrize("bg", [1, 2])
+def test_interleaved_block_geometry(pkg, orc, bg):
+    """NRLDPC_Z64I_LIST: NCW codewords of a small lifting size Zr interleaved (ring position z * NCW + c) in one workgroup of the
+    block geometry of the virtual size Zr * NCW.  Every entry: a batch that leaves the last workgroup one codeword (the other
+    lanes decode zeros) and one smaller than a workgroup; every row active and two pruned layer counts (the run-time-prefix
+    builds); after 1, 2, 3 iterations where nothing converges, 25 fixed iterations, and the parity stop in the waterfall for
+    the modes the entry serves (the others run the kernels of the tests above)."""
+    import importlib
+    bld = importlib.import_module("ldpc-3gpp-matlab_amd.build")
+    rng = np.random.default_rng(9100 + bg)
+    rows = BG_DIMS[bg][0]
+    entries = [(z, n, m) for b, z, n, m in bld.Z64I if b == bg]
+    assert entries
+    for Z, ncw, mode in entries:
+        for nl in (0, 7 if bg == 2 else 13, rows - 3):
+            w = _waterfall_esn0(bg, nl or rows)
+            for B in (ncw + 1, max(1, ncw - 1)):
+                if mode & 1:
+                    for iters in (1, 2, 3):
+                        run_case(pkg, orc, rng, bg, Z, B, w - 2.5, iters, nl=nl, et=False, app=False,
+                                 dt=np.float16 if (Z + iters) % 2 else np.float32)
+                if mode & (2 if nl == 0 else 4):
+                    run_case(pkg, orc, rng, bg, Z, B, w + 0.2, 14, nl=nl, et=True, app=False)
+            if mode & 1:
+                run_case(pkg, orc, rng, bg, Z, 2 * ncw + 1, w, 25, nl=nl, et=False, app=False)
+
+
+@pytest.mark.parametrize("bg", [1, 2])
 def test_z384_kernel_variants(pkg, orc, bg):
     """The compile-time Z=384 kernel has three builds (plain fixed-iteration, full-H with early
     termination / soft output, pruned layers); each against the oracle, with odd batch sizes so that a
