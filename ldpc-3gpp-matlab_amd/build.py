@@ -40,11 +40,11 @@ Z64I = [
     (1, 2, 128, 5), (1, 3, 128, 5), (1, 4, 64, 5), (1, 5, 48, 5), (1, 6, 64, 5), (1, 7, 32, 5), (1, 8, 32, 7), (1, 9, 28, 5), (1, 10, 24, 1), (1, 11, 20, 1),
     (1, 12, 32, 1), (1, 13, 16, 1), (1, 14, 16, 1), (1, 15, 16, 1), (1, 16, 16, 5), (1, 18, 14, 1), (1, 20, 12, 1), (1, 22, 10, 1), (1, 24, 16, 1), (1, 26, 8, 1),
     (1, 28, 8, 1), (1, 30, 8, 1), (1, 32, 8, 1), (1, 36, 7, 7), (1, 40, 6, 1), (1, 44, 5, 7), (1, 48, 8, 1), (1, 52, 4, 1), (1, 56, 4, 1), (1, 60, 4, 1),
-    (1, 64, 4, 1), (1, 72, 5, 1), (1, 80, 3, 7), (1, 96, 4, 7), (1, 104, 2, 1), (1, 112, 2, 1), (1, 120, 2, 1), (1, 128, 2, 1), (1, 192, 2, 1), (2, 2, 128, 5),
-    (2, 4, 64, 5), (2, 5, 48, 5), (2, 7, 32, 4), (2, 8, 32, 5), (2, 9, 28, 5), (2, 10, 24, 1), (2, 11, 20, 1), (2, 13, 16, 1), (2, 14, 16, 5), (2, 15, 16, 1),
-    (2, 16, 16, 1), (2, 18, 14, 1), (2, 20, 12, 1), (2, 22, 10, 1), (2, 26, 8, 1), (2, 28, 8, 1), (2, 30, 8, 1), (2, 32, 8, 1), (2, 36, 7, 3), (2, 40, 6, 1),
-    (2, 44, 5, 7), (2, 52, 4, 1), (2, 56, 4, 1), (2, 60, 4, 1), (2, 64, 4, 1), (2, 80, 3, 7), (2, 88, 5, 1), (2, 96, 4, 1), (2, 104, 2, 1), (2, 112, 2, 1),
-    (2, 120, 2, 1), (2, 128, 2, 1), (2, 160, 3, 1),
+    (1, 64, 4, 1), (1, 72, 5, 1), (1, 80, 3, 7), (1, 96, 4, 7), (1, 104, 2, 1), (1, 112, 2, 1), (1, 120, 2, 1), (1, 128, 2, 1), (1, 160, 1, 6), (1, 192, 2, 1),
+    (2, 2, 128, 5), (2, 4, 64, 5), (2, 5, 48, 5), (2, 7, 32, 4), (2, 8, 32, 5), (2, 9, 28, 5), (2, 10, 24, 1), (2, 11, 20, 1), (2, 13, 16, 1), (2, 14, 16, 5),
+    (2, 15, 16, 1), (2, 16, 16, 1), (2, 18, 14, 1), (2, 20, 12, 1), (2, 22, 10, 1), (2, 26, 8, 1), (2, 28, 8, 1), (2, 30, 8, 1), (2, 32, 8, 1), (2, 36, 7, 3),
+    (2, 40, 6, 1), (2, 44, 5, 7), (2, 52, 4, 1), (2, 56, 4, 1), (2, 60, 4, 1), (2, 64, 4, 1), (2, 80, 3, 7), (2, 88, 5, 1), (2, 96, 4, 1), (2, 104, 2, 1),
+    (2, 112, 2, 1), (2, 120, 2, 1), (2, 128, 2, 1), (2, 160, 3, 1), (2, 176, 1, 5),
 ]
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7), (2, 208, 21)]

@@ -99,6 +99,16 @@ constexpr int z64_ilv() {
     return 1;
 #endif
 }
+// ... NCW = 1 included (-DNRLDPC_Z64_ILV=1): one codeword of the lifting size itself in that kernel.  Measured for Z = 144 ... 384
+// against the split / row kernels of nrldpc_decode_z64s.h / this file: within +-3 % or slower everywhere except BG1 Z = 160
+// with the parity stop and BG2 Z = 176 (profiles/r04_ilv_ab.txt) -- the interleaved units gain from their shape, not from the kernel
+constexpr bool z64_ilvm() {
+#ifdef NRLDPC_Z64_ILV
+    return true;
+#else
+    return false;
+#endif
+}
 
 // Row waves per half of a packed workgroup: 1, 2 or 4 -- the first of these that fills 80 % of its lanes, else the best filled.
 // Measured (one session each, fixed 25 / parity stop): for Z <= 32 two-wave halves gain 2-10 % at fixed iterations where they
@@ -113,7 +123,7 @@ constexpr int z64p_rw(int BG, int Z) {
     return NRLDPC_Z64P_RW;
 #endif
     (void)BG;
-    if (z64_ilv() > 1) return Z / z64_blk(Z); // interleaved block geometry: the virtual size's waves per codeword
+    if (z64_ilvm()) return Z / z64_blk(Z); // interleaved block geometry: the virtual size's waves per codeword
     // Large lifting sizes of BG1 that do not split into full waves in the block geometry (11 or 3 times a power of two: blocks of
     // 44-48 rows leave 25-31 % of the lanes idle): 6-wave halves -- the 12-wave workgroup shape of Z = 384's split kernel -- carry
     // 352 rows (4 x 88, 2 x 176, 1 x 352) or 384 (4 x 96).  Measured against the kernels these sizes ran before, one session
@@ -130,7 +140,7 @@ constexpr int z64p_rw(int BG, int Z) {
     }
     return best;
 }
-constexpr int z64p_ncw(int BG, int Z) { return z64_ilv() > 1 ? z64_ilv() : 64 * z64p_rw(BG, Z) / Z; } // codewords per packed workgroup
+constexpr int z64p_ncw(int BG, int Z) { return z64_ilvm() ? z64_ilv() : 64 * z64p_rw(BG, Z) / Z; } // codewords per packed workgroup
 
 // Rows per wave ("block"): 64 when 64 | Z, else the largest divisor of Z below 64 that is a multiple of 4.
 // A wave then owns B consecutive rows and its lanes B..63 retire at kernel entry (Z = 240 -> 4 waves of 60
@@ -139,7 +149,7 @@ constexpr int z64p_ncw(int BG, int Z) { return z64_ilv() > 1 ? z64_ilv() : 64 * 
 constexpr int z64_blk(int Z) {
     if (z64_packed(Z)) return Z; // the whole ring: every shift is an offset from one base address
     if (Z % 64 == 0) return 64;
-    if (z64_ilv() > 1) { // interleaved units read and write single words only: any divisor will do (252 = 4 x 63, 220 = 4 x 55)
+    if (z64_ilvm()) { // interleaved units read and write single words only: any divisor will do (252 = 4 x 63, 220 = 4 x 55)
         for (int b = 63; b >= 4; --b)
             if (Z % b == 0) return b;
     }

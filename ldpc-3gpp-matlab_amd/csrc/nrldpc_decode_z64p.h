@@ -16,7 +16,7 @@ namespace nrldpc {
 
 template <int BG, int ZC, int NL = BGT<BG>::ROWS> struct Z64P : Z64<BG, ZC, 1, NL> {
     using B = Z64<BG, ZC, 1, NL>;
-    static constexpr bool ILVM = B::ILV > 1;          // interleaved BLOCK geometry (z64_ilv): ZC is the virtual size
+    static constexpr bool ILVM = z64_ilvm();          // interleaved BLOCK geometry (z64_ilv): ZC is the virtual size
     static_assert(ILVM ? !B::PACKED : (B::PACKED && B::NWV == 1), "packed geometry, or the block geometry with interleaved codewords");
     static constexpr int RW = z64p_rw(BG, ZC);       // row waves per half
     static constexpr int NCW = z64p_ncw(BG, ZC);     // codewords per workgroup
@@ -51,7 +51,7 @@ template <int BG, int ZC, int NL> constexpr int z64p_wpe() {
 // NL: the active rows 0..NL-1, a compile-time fact (all rows, or one of the pruned counts of NRLDPC_Z64P_NL_LIST)
 // ILVT: the unit's interleave factor, a template argument ONLY so that it is part of the kernel's name -- the units of 128 x 2,
 // 64 x 4, 32 x 8 ... all instantiate <BG, 256, ...>, a kernel handle is a weak symbol, and the linker would keep the first one's
-template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS, int ILVT = z64_ilv()>
+template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS, int ILVT = (z64_ilvm() ? 1000 + z64_ilv() : 0)>
 __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>())) void nrldpc_decode_z64p_kernel(const DecArgs a) {
     using G = Z64P<BG, ZC, NL>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
 
 template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t launch_z64p_t(const DecArgs& a, hipStream_t s) {
     using G = Z64P<BG, ZC, NL>;
-    auto k = nrldpc_decode_z64p_kernel<BG, ZC, ETP, NL, z64_ilv()>;
+    auto k = nrldpc_decode_z64p_kernel<BG, ZC, ETP, NL, (z64_ilvm() ? 1000 + z64_ilv() : 0)>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {};

@@ -194,5 +194,5 @@ def test_kernel_lists_of_the_build_and_of_the_dispatch_agree():
     assert all(z in all_z for _, z in bld.Z64_PAIRS + bld.Z64P_PAIRS + [(b, z) for b, z, _ in bld.Z64PR])
     # interleaved block geometry: the virtual size is a block-geometry shape of full (or nearly full) waves, at most 8 per half
     # (at most 8 waves of at most 64 rows per half, and a mode that serves something)
-    assert all(z in all_z and 2 <= n and z * n <= 512 and 1 <= m <= 7 for _, z, n, m in bld.Z64I)
+    assert all(z in all_z and 1 <= n and z * n <= 512 and 1 <= m <= 7 for _, z, n, m in bld.Z64I)
     assert len({(b, z) for b, z, _, _ in bld.Z64I}) == len(bld.Z64I)
