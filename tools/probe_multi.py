@@ -1,0 +1,33 @@
+import importlib, sys, time, os
+import numpy as np, torch
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+pkg = importlib.import_module("ldpc-3gpp-matlab_amd")
+import bench_configs as bc
+rng = np.random.default_rng(4)
+B = 8192
+draws = [(int(rng.integers(1, 3)), int(rng.choice(bc.ALL_Z))) for _ in range(B)]
+buckets = {}
+for key in draws: buckets[key] = buckets.get(key, 0) + 1
+work = []
+for (bg, Z), n in sorted(buckets.items()):
+    rows, cols, kb = bc.DIMS[bg]
+    codec = pkg.Codec(bg, Z, max_iter=25, early_term=True, alpha=0.625, llr_dtype=np.float16)
+    info, llr = bc.synth(codec, bg, Z, n, cols * Z, 3.0, Z)
+    hard = torch.empty((n, kb * Z), device="cuda", dtype=torch.uint8)
+    iters = torch.zeros(n, device="cuda", dtype=torch.int32)
+    work.append((codec, llr, hard, n, kb * Z, iters, bg, Z))
+s0 = torch.cuda.current_stream().cuda_stream
+args = ([w[0] for w in work], [w[1].data_ptr() for w in work], [w[3] for w in work], [w[2].data_ptr() for w in work], [w[5].data_ptr() for w in work], s0)
+for rep in range(6):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pkg.decode_multi_dev(*args)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("call returns after %.3f ms, all done after %.3f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+tot = 0; cnt = 0; strag = []
+for w in work:
+    it = w[5].cpu().numpy(); tot += it.sum(); cnt += it.size
+    if (it >= 25).any(): strag.append((w[6], w[7], int((it >= 25).sum()), w[3]))
+print("mean iterations %.2f over %d codewords; buckets with codewords at the cap:" % (tot / cnt, cnt), strag)
