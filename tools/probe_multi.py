@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Where the wall time of one mixed-batch call (BASELINE configs[3], nrldpc_decode_multi_dev) goes: when the call returns to the host,\nwhen the device is done, the iteration counts behind it.  NRLDPC_MULTI_Z64_MIN_ROWS / NRLDPC_MULTI_ONE_STREAM are the A/B switches."""
 import importlib, sys, time, os
 import numpy as np, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
@@ -31,3 +33,5 @@ for w in work:
     it = w[5].cpu().numpy(); tot += it.sum(); cnt += it.size
     if (it >= 25).any(): strag.append((w[6], w[7], int((it >= 25).sum()), w[3]))
 print("mean iterations %.2f over %d codewords; buckets with codewords at the cap:" % (tot / cnt, cnt), strag)
+mx = sorted(((int(w[5].max().item()), w[6], w[7], w[3]) for w in work), reverse=True)
+print("largest iteration counts (iterations, BG, Z, codewords in the bucket):", mx[:10])
