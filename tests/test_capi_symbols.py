@@ -196,3 +196,12 @@ def test_kernel_lists_of_the_build_and_of_the_dispatch_agree():
     # (at most 8 waves of at most 64 rows per half, and a mode that serves something)
     assert all(z in all_z and 1 <= n and z * n <= 512 and 1 <= m <= 7 for _, z, n, m in bld.Z64I)
     assert len({(b, z) for b, z, _, _ in bld.Z64I}) == len(bld.Z64I)
+    for b, z, n, m in bld.Z64I:  # the workgroup shape z64_blk / Z64P derive from the virtual size (nrldpc_decode_z64.h, _z64p.h)
+        zc = z * n
+        blk = 64 if zc % 64 == 0 else max(d for d in range(4, 64) if zc % d == 0)
+        waves = zc // blk
+        assert 2 * waves <= 16 and blk >= 40, (b, z, n)  # at most 1024 threads; no shape with more than 3/8 of the lanes idle
+        nc, ext = (26, 42) if b == 1 else (14, 38)
+        image = nc * (256 + (zc + 64) * 4) + 256 + 4 * ((n + 1 + 3) // 4 * 4)
+        assert image <= 160 * 1024 and nc * (256 + (zc + 64) * 4) < 65536, (b, z, n)  # LDS budget; 16-bit LDS immediates
+        assert n + 1 <= 2 * waves * 64  # the flag words are cleared by one pass of the workgroup's threads
