@@ -39,7 +39,7 @@ for case in cases:
             if its.mean() > 10: lo = mid
             else: hi = mid
         c.close()
-        esn0 = 0.5 * (lo + hi)
+        esn0 = 0.5 * (lo + hi) + float(os.environ.get("WF_OFFSET", "0"))  # WF_OFFSET: dB away from the waterfall
     B = max(4096, (4096 * 384 // Z) // 256 * 256)
     nb = min(B, max(256, 98304 // Z // 256 * 256))  # distinct noisy codewords (the parity stop's time depends on which ones share a workgroup)
     B = B // nb * nb
