@@ -317,6 +317,7 @@ def dry_run(args, torch):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if args.backend == "nccl" else args.backend)
+        assert dist.get_world_size() == args.gpus
 
     def barrier():
         if dist is not None:
@@ -350,10 +351,37 @@ def dry_run(args, torch):
         print(json.dumps({"metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
                           "dry_run": True, "value": None, "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak",
+                          "comm": {"backend": dist.get_backend() if dist is not None else None, "world_size": world},
                           "cfg5_strong": leg}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def check_or_start_ranks(args):
+    """`--gpus N` means N ranks, one per GPU (plot_BLER_vs_SNR.m:23-27: "parallel instances ... aggregated").  Launched the
+    driver's way (torch.distributed.run sets WORLD_SIZE) the rank count must BE N: a line that says n_gpus: 1 for --gpus 8 is
+    refused, not printed.  Launched plainly -- `python bench.py --gpus 8`, WORLD_SIZE unset -- this process starts the N ranks
+    itself (re-exec under torch.distributed.run on 127.0.0.1, a free port) and hands their output and exit code through."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (python -m torch.distributed.run "
+                             "--nproc-per-node %d ... bench.py --gpus %d), or run `python bench.py --gpus %d` without a launcher "
+                             "and it starts the ranks itself" % (args.gpus, env_world, args.gpus, args.gpus, args.gpus))
+        return
+    if args.gpus == 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %d ranks: %s" % (args.gpus, args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -374,6 +402,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="test aid: run the rank protocol (init, barrier, timed loop "
                     "bracket, max-over-ranks, one JSON line) without touching a GPU; the line says dry_run and is no result")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    check_or_start_ranks(args)
 
     import torch
     torch.set_num_threads(4)  # host-side tensor copies only; idle OpenMP workers would spend the container's CPU quota
@@ -381,12 +412,16 @@ def main():
         return dry_run(args, torch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and this framework has no CPU path")
+    if not args.share_gpu and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible (one rank per GPU; --share-gpu is the "
+                         "1-GPU test aid)" % (args.gpus, torch.cuda.device_count()))
     nrldpc = importlib.import_module("ldpc-3gpp-matlab_amd")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))  # == args.gpus: check_or_start_ranks
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    comm = {"backend": None, "world_size": 1}
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -394,8 +429,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        # what the communication library itself says (nccl IS RCCL on ROCm); carries only the barrier and two small reductions
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None}
+        if comm["world_size"] != args.gpus:
+            raise SystemExit("bench.py: the process group holds %d ranks, --gpus says %d" % (comm["world_size"], args.gpus))
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -543,7 +581,7 @@ def main():
         out = {
             "metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
             "value": value, "unit": "Gbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "comm": comm,
             "vs_baseline": None, "dtype": "i8 messages / integer-valued f32 a-posteriori (fp16 LLR input)",
             "data": "synthetic",
             "config": {"workload": "BG1 Z=384 (K=8448) R=1/3, 25 layered min-sum iterations, no early termination, "

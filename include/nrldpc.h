@@ -55,14 +55,33 @@ typedef struct nrldpc_codec* nrldpc_handle;
  * nrldpc_abi_version() returns the revision the loaded library was built with (the library is loaded by path and has
  * no SONAME; a binding checks this number at load time, as ldpc-3gpp-matlab_amd/_capi.py does).
  * Revision 4 adds nrldpc_decode_packed and the CRC-aided stop (early_term = 2; crc_poly, crc_len, crc_bits at the tail of
- * nrldpc_cfg). */
-#define NRLDPC_ABI_VERSION 4
+ * nrldpc_cfg).
+ * Revision 5 makes the active layer count a property of the CALL, not of the handle: nrldpc_set_layers / nrldpc_last_layers /
+ * nrldpc_count_layers / nrldpc_pool_set_layers / nrldpc_set_llr_dtype and the value NRLDPC_LAYERS_AUTO (-1) for nrldpc_cfg.n_layers -- see "Active
+ * layers" below; and adds nrldpc_pool_decode_packed.  nrldpc_cfg and nrldpc_dims keep their revision-4 layout and size. */
+#define NRLDPC_ABI_VERSION 5
+
+/* Active layers.  The reference always decodes the full H (NRLDPCDecoder.m:120).  A base-graph row i >= 4 owns the degree-1
+ * extension-parity column kb + i; when every codeword of a call holds LLR 0 in that column (not transmitted: rate matching
+ * stopped below it, NRLDPCDecoder.m:216-234) the row's check-to-variable messages are identically zero and the row can be left
+ * out -- exactly, for sum-product and min-sum alike -- as can every row above it that is in the same
+ * state.  At the reference's own defaults (plot_BLER_vs_SNR.m:29-41: BG2, R = 1/3) that is 21 of 42 rows, at R = 8/9 on BG1 5 of 46.
+ *   n_layers = 0 (NRLDPC_LAYERS_ALL): every row;  4..46 / 4..42: that many rows, the caller vouches for the zeros;
+ *   NRLDPC_LAYERS_AUTO: read off the data, per call -- n = max(4, c - kb + 1) for the highest base-graph column c of the call's
+ *   codewords that holds a value other than +-0 and NaN (NaN is ingested as 0).  Exact for any rv_id, repetition, LBRM or
+ *   HARQ-combined buffer because nothing is assumed about how the zeros came about.  Host-pointer entry points scan the caller's
+ *   array from the top column down on the copy threads (a column block that is all zero is read once and never quantised or
+ *   sent); device-pointer entry points run a pre-pass kernel and read one integer back, i.e. they synchronise `stream` once
+ *   before the launch.  With cfg.alpha == 0 the check-node rule follows the count in use (nrldpc_default_rule). */
+#define NRLDPC_LAYERS_ALL 0
+#define NRLDPC_LAYERS_AUTO (-1)
 
 typedef struct nrldpc_cfg {
     uint32_t struct_size; /* = sizeof(nrldpc_cfg); nrldpc_create refuses any other value (NRLDPC_ERR_ARG)      */
     int32_t bg;         /* 1 or 2                                     (NRLDPC.m:28)               */
     int32_t Z;          /* lifting size Z_c, one of the 51 of Table 5.3.2-1 (NRLDPC.m:409-411)    */
-    int32_t n_layers;   /* base rows to decode, 4..46 (BG1) / 4..42 (BG2); 0 = all (reference: all) */
+    int32_t n_layers;   /* base rows to decode, 4..46 (BG1) / 4..42 (BG2); 0 = all (reference: all); NRLDPC_LAYERS_AUTO = read
+                           off each call's LLRs ("Active layers" above); nrldpc_set_layers changes it between calls */
     int32_t max_iter;   /* 'MaximumIterationCount' (NRLDPCDecoder.m:41,120); 1..2000              */
     int32_t early_term; /* 0 = always max_iter iterations; 1 = stop a codeword when all active parity checks hold (the
                            reference: 'Parity check satisfied', NRLDPCDecoder.m:120); 2 = that, or when the CRC of the
@@ -95,14 +114,30 @@ typedef struct nrldpc_dims {
     int32_t nrows, ncols, kb; /* 46,68,22 or 42,52,10 */
     int32_t i_ls;             /* set index (get_3gpp_set_index.m) */
     int32_t K, N_cw;          /* kb*Z, ncols*Z */
-    int32_t n_layers;         /* resolved active layer count */
-    float alpha, beta;        /* resolved check-node rule (beta in LLR units) */
+    int32_t n_layers;         /* active layer count of the next call: 4..rows, or NRLDPC_LAYERS_AUTO */
+    float alpha, beta;        /* resolved check-node rule (beta in LLR units); under NRLDPC_LAYERS_AUTO with cfg.alpha == 0:
+                                 the rule of the last call's count (before the first call: of all rows) */
 } nrldpc_dims;
 
 int nrldpc_abi_version(void); /* NRLDPC_ABI_VERSION of the library's build */
 int nrldpc_create(const nrldpc_cfg* cfg, nrldpc_handle* out);
 void nrldpc_destroy(nrldpc_handle h);
 int nrldpc_get_dims(nrldpc_handle h, nrldpc_dims* out);
+
+/* Active layer count of the calls that follow (every decode entry point, nrldpc_decode_multi_dev included): NRLDPC_LAYERS_ALL,
+ * 4..rows of the base graph, or NRLDPC_LAYERS_AUTO.  No device work, no reallocation: the kernels take the count as a launch
+ * argument.  With cfg.alpha == 0 the check-node rule becomes nrldpc_default_rule(bg, count) -- a call gives bit for bit what a
+ * handle created with that n_layers gives.  NRLDPC_ERR_UNSUPPORTED for any other value.
+ * (A System object's rate is tunable between step() calls -- G, rv_id: NRLDPC.m:51-85 -- so the count is too.) */
+int nrldpc_set_layers(nrldpc_handle h, int32_t n_layers);
+/* LLR element type of the calls that follow (NRLDPC_LLR_*; NRLDPC_LLR_F64 for host pointers only): a gateway whose caller holds
+ * `single` or `double` arrays hands each over as it is, through one handle (staging buffers grow on demand). */
+int nrldpc_set_llr_dtype(nrldpc_handle h, int32_t llr_dtype);
+/* The count the most recent decode call of this handle ran with (what NRLDPC_LAYERS_AUTO found); 0 before the first call. */
+int nrldpc_last_layers(nrldpc_handle h, int32_t* n_layers);
+/* What NRLDPC_LAYERS_AUTO finds for `batch` codewords at the HOST address llr ([batch][ncols*Z] of llr_dtype, NRLDPC_LLR_*):
+ * the layer count, 4..rows; -1 on invalid arguments (text via nrldpc_last_error).  Host function, no device needed. */
+int nrldpc_count_layers(int32_t bg, int32_t Z, const void* llr, int32_t batch, int32_t llr_dtype);
 
 /* Decode `batch` codewords.  llr: [batch][ncols*Z] of cfg.llr_dtype.  hard: [batch][K] bytes in
  * {0,1} (the K x 1 logical of comm.LDPCDecoder).  iters_out (nullable): iterations executed per
@@ -145,6 +180,12 @@ typedef struct nrldpc_pool* nrldpc_pool_handle;
 int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t n_devices, int32_t chunks_per_device,
                        nrldpc_pool_handle* out);
 int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out);
+/* nrldpc_pool_decode with bit-packed hard decisions ([batch][ceil(K/8)], as nrldpc_decode_packed): what a MEX gateway calls */
+int nrldpc_pool_decode_packed(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard_packed, int32_t* iters_out);
+/* nrldpc_set_layers for every handle of the pool.  Under NRLDPC_LAYERS_AUTO the count is found ONCE per call over the whole
+ * batch (host form: before the chunks are dealt; device form: every shard scans its slice, the maximum is taken, then every
+ * shard launches), so the result does not depend on how the batch is cut. */
+int nrldpc_pool_set_layers(nrldpc_pool_handle p, int32_t n_layers);
 /* The same for data that is already ON the devices: shard i (entry i of device_ids) decodes batch[i] codewords from
  * d_llr[i] into d_hard[i] (and d_iters[i] when d_iters and d_iters[i] are non-null); every pointer of shard i is
  * device memory of device_ids[i], in cfg.llr_dtype (F32 / F16).  One host thread per shard launches on the shard's

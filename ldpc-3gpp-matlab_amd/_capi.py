@@ -25,7 +25,8 @@ class NRLDPCError(RuntimeError):
     identifier = "ldpc_3gpp_matlab:Error"
 
 
-ABI_VERSION = 4  # NRLDPC_ABI_VERSION of include/nrldpc.h
+ABI_VERSION = 5  # NRLDPC_ABI_VERSION of include/nrldpc.h
+LAYERS_ALL, LAYERS_AUTO = 0, -1  # NRLDPC_LAYERS_*
 
 
 class Cfg(C.Structure):
@@ -73,7 +74,8 @@ EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev",  "nrldpc_crc_check_
            "nrldpc_decode_multi_dev", "nrldpc_quantise_llr", "nrldpc_encode", "nrldpc_encode_dev", "nrldpc_set_timing", "nrldpc_last_kernel_ms",
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version", "nrldpc_build_id", "nrldpc_kernel_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
-           "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version", "nrldpc_decode_packed"]
+           "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version", "nrldpc_decode_packed",
+           "nrldpc_set_layers", "nrldpc_set_llr_dtype", "nrldpc_last_layers", "nrldpc_count_layers", "nrldpc_pool_set_layers", "nrldpc_pool_decode_packed"]
 
 _lib = None
 
@@ -140,6 +142,12 @@ def load():
     L.nrldpc_rate_match_dev.argtypes = [C.POINTER(TbParams), vp, i32, vp, vp]
     L.nrldpc_pool_create.argtypes = [C.POINTER(Cfg), C.POINTER(i32), i32, i32, C.POINTER(vp)]
     L.nrldpc_pool_decode.argtypes = [vp, vp, i32, vp, vp]
+    L.nrldpc_pool_decode_packed.argtypes = [vp, vp, i32, vp, vp]
+    L.nrldpc_pool_set_layers.argtypes = [vp, i32]
+    L.nrldpc_set_layers.argtypes = [vp, i32]
+    L.nrldpc_set_llr_dtype.argtypes = [vp, i32]
+    L.nrldpc_last_layers.argtypes = [vp, C.POINTER(i32)]
+    L.nrldpc_count_layers.argtypes = [i32, i32, vp, i32, i32]
     L.nrldpc_pool_last_split.argtypes = [vp, C.POINTER(i32)]
     L.nrldpc_pool_decode_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp)]
     L.nrldpc_pool_size.argtypes = [vp]
@@ -186,6 +194,7 @@ class Codec:
                  llr_dtype=np.float32, device_id=0, max_batch=0, beta=0.0, crc=None):
         """alpha = 0: the library picks the check-node rule (alpha, beta) by rate (nrldpc_default_rule);
         otherwise message magnitude = max(alpha*min - beta, 0), beta in LLR units.
+        n_layers: 0 = every row, 4..rows, or LAYERS_AUTO (-1) = read off each call's LLRs; set_layers() changes it between calls.
         crc = (poly with its x^L term, L, K'): the CRC-aided stop (nrldpc_cfg.early_term = 2) on the first K' information bits."""
         L = load()
         self._lib = L
@@ -206,6 +215,25 @@ class Codec:
         if getattr(self, "_h", None) and self._h.value:
             self._lib.nrldpc_destroy(self._h)
             self._h = C.c_void_p()
+
+    def set_layers(self, n_layers):
+        """nrldpc_set_layers: active layer count of the calls that follow (0 all, 4..rows, LAYERS_AUTO); no device work."""
+        check(self._lib.nrldpc_set_layers(self._h, int(n_layers)))
+        d = Dims(C.sizeof(Dims))
+        check(self._lib.nrldpc_get_dims(self._h, C.byref(d)))
+        self.n_layers, self.alpha, self.beta = d.n_layers, float(d.alpha), float(d.beta)
+
+    def set_llr_dtype(self, llr_dtype):
+        """nrldpc_set_llr_dtype: element type of the arrays the calls that follow hand over (np.float32 / float16 / float64)."""
+        dt = np.dtype(llr_dtype)
+        check(self._lib.nrldpc_set_llr_dtype(self._h, _NP2DT[dt]))
+        self.llr_dtype = dt
+
+    def last_layers(self):
+        """nrldpc_last_layers: the count the most recent decode call ran with (what LAYERS_AUTO found)."""
+        n = C.c_int32()
+        check(self._lib.nrldpc_last_layers(self._h, C.byref(n)))
+        return int(n.value)
 
     def __del__(self):
         try:
@@ -296,6 +324,21 @@ class CodecPool:
         iters = np.empty(B, np.int32) if want_iters else None
         check(self._lib.nrldpc_pool_decode(self._p, _ptr(llr), B, _ptr(hard), _ptr(iters)))
         return (hard, iters) if want_iters else hard
+
+    def decode_packed(self, llr, want_iters=False):
+        """nrldpc_pool_decode_packed: as decode(), hard decisions bit-packed [B][ceil(K/8)] (Codec.decode_packed)."""
+        llr = np.ascontiguousarray(llr, self.llr_dtype)
+        if llr.size % self.N_cw:
+            raise NRLDPCError("llr should hold a whole number of codewords of length %d" % self.N_cw)
+        B = llr.size // self.N_cw
+        packed = np.empty((B, (self.K + 7) // 8), np.uint8)
+        iters = np.empty(B, np.int32) if want_iters else None
+        check(self._lib.nrldpc_pool_decode_packed(self._p, _ptr(llr), B, _ptr(packed), _ptr(iters)))
+        return (packed, iters) if want_iters else packed
+
+    def set_layers(self, n_layers):
+        """nrldpc_pool_set_layers (LAYERS_AUTO: found once per call over the whole batch)."""
+        check(self._lib.nrldpc_pool_set_layers(self._p, int(n_layers)))
 
     def decode_dev(self, d_llr, batch, d_hard, d_iters=None):
         """nrldpc_pool_decode_dev: shard i decodes batch[i] codewords at device address d_llr[i] (memory of
@@ -391,6 +434,18 @@ def quantise_llr(llr, llr_scale=8):
     q = np.empty(llr.shape, np.int8)
     neg = load().nrldpc_quantise_llr(_ptr(q), _ptr(llr), llr.size, kind, int(llr_scale))
     return q, bool(neg)
+
+
+def count_layers(bg, Z, llr):
+    """nrldpc_count_layers: what LAYERS_AUTO finds for host LLRs [batch][ncols*Z] (f32 / f16 / f64).  No device needed."""
+    llr = np.ascontiguousarray(llr)
+    cols = {1: 68, 2: 52}[int(bg)]
+    if llr.size % (cols * int(Z)):
+        raise NRLDPCError("llr should hold a whole number of codewords")
+    n = load().nrldpc_count_layers(int(bg), int(Z), _ptr(llr), llr.size // (cols * int(Z)), _NP2DT[llr.dtype])
+    if n < 0:
+        raise NRLDPCError((load().nrldpc_last_error() or b"").decode())
+    return n
 
 
 def default_rule(bg, n_layers=0):

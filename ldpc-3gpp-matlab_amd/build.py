@@ -162,6 +162,9 @@ def build_lib(force=False, verbose=False, jobs=None):
                 "-DNRLDPC_Z64S_DUAL=0", "-DNRLDPC_Z64I_MODE=%d" % mode]) for bg, z, ncw, mode in Z64I]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64_NL]
+    # every decoder unit gets a name space of its own for the -D-dependent templates (NRLDPC_UNIT, nrldpc_decode_z64.h)
+    units = [(src, obj, defs + (["-DNRLDPC_UNIT=u_" + os.path.splitext(os.path.basename(obj))[0]] if os.path.basename(src) in (Z64_SOURCE, Z64P_SOURCE) else []))
+             for src, obj, defs in units]
     # An object is reused only when it was compiled from exactly these inputs: contents of its source and of every header
     # it includes (transitively, by scanning #include "..." lines: a change to the C ABI does not recompile 130 decoder
     # units), the flags and the -D list (sidecar <obj>.id) -- never by modification time, which a snapshot copy, rsync -t or

@@ -264,6 +264,11 @@ public:
     }
     // f(worker, nworkers) on every worker; returns when all are done
     void run(std::function<void(int, int)> f) {
+        start(std::move(f));
+        finish();
+    }
+    // the same in two halves: the caller's thread is free between them (it takes finished chunks' results out meanwhile)
+    void start(std::function<void(int, int)> f) {
         job_ = std::move(f);
         pending_.store((int)th_.size(), std::memory_order_relaxed);
         {
@@ -271,6 +276,9 @@ public:
             gen_.fetch_add(1, std::memory_order_release);
         }
         if (sleepers_.load() > 0) cv_.notify_all();
+    }
+    bool done() const { return pending_.load(std::memory_order_acquire) == 0; }
+    void finish() {
         // poll for the usual sub-millisecond job; on an oversubscribed host (several handles decoding at once, each with
         // its own pool) give the core away instead
         const auto t0 = std::chrono::steady_clock::now();
@@ -296,6 +304,34 @@ public:
         });
         return neg.load() != 0;
     }
+    // the same for the first `act` elements of each of n_rows rows that are `pitch` elements apart in src; dst is COMPACT
+    // ([n_rows][act]); the compact range [c_lo, c_hi) only (multiples of 64 or the end) -- the rest of a row is known to be zero
+    // and is neither read nor sent (nrldpc.h "Active layers")
+    // (two halves, see start / finish: quantise_rows_start, then quantise_rows_finish() = "a -inf was met")
+    std::atomic<int> neg_{0};
+    void quantise_rows_start(int8_t* dst, const void* src, size_t act, size_t pitch, size_t c_lo, size_t c_hi, int kind, float scale) {
+        neg_.store(0, std::memory_order_relaxed);
+        const size_t es = kind == NRLDPC_HQ_F64 ? 8 : kind == NRLDPC_HQ_F16 ? 2 : 4, n = c_hi - c_lo;
+        start([=](int w, int nw) {
+            const size_t per = ((n + nw - 1) / nw + 63) & ~(size_t)63, lo = c_lo + std::min(n, per * w), hi = std::min(c_hi, lo + per);
+            for (size_t pos = lo; pos < hi;) {
+                const size_t r = pos / act, in_row = pos - r * act, len = std::min(hi - pos, act - in_row);
+                if (nrldpc_quantise_i8(dst + pos, static_cast<const char*>(src) + (r * pitch + in_row) * es, len, kind, scale))
+                    neg_.store(1, std::memory_order_relaxed);
+                pos += len;
+            }
+        });
+    }
+    bool quantise_rows_finish() {
+        finish();
+        return neg_.load() != 0;
+    }
+    // NRLDPC_LAYERS_AUTO: highest block in [first, nblocks) holding anything but +-0 / NaN in any of n_cw codewords (nrldpc_host_quant.h)
+    int top_block(const void* src, int kind, size_t n_cw, int Z, int nblocks, int first) {
+        int best = first - 1;
+        run([=, &best](int w, int nw) { nrldpc_top_block(src, kind, n_cw, (size_t)w, (size_t)nw, Z, nblocks, first, &best); });
+        return best;
+    }
     // dst[i] = src[i] for n bytes, or float(dst) = double(src) for n elements when narrow
     void move(void* dst, const void* src, size_t n, bool narrow) {
         run([=](int w, int nw) {
@@ -316,8 +352,14 @@ public:
 struct nrldpc_codec {
     nrldpc_cfg cfg;
     nrldpc::Schedule sched;
-    float alpha = 0.75f, beta = 0.0f; // beta in LLR units; the kernels get beta*scale
+    float alpha = 0.75f, beta = 0.0f; // beta in LLR units; the kernels get beta*scale (the rule of `rule_layers` rows)
     int scale = 8;
+    // active layers (ABI revision 5): a property of the call.  layers = what the next call uses: 4..rows, or NRLDPC_LAYERS_AUTO;
+    // last_layers = what the last call ran with; rule_auto: cfg.alpha == 0, the check-node rule follows the count in use
+    int layers = 0, last_layers = 0, rule_layers = 0;
+    bool rule_auto = false;
+    DevBuf<int32_t> d_best; // NRLDPC_LAYERS_AUTO on device pointers: the pre-pass kernel's result ...
+    PinBuf pin_best;        // ... and where the host reads it
     // device tables
     DevBuf<int32_t> d_rot;
     DevBuf<uint32_t> d_crc; // x^(crc_bits-1-i) mod g, i < crc_bits: the CRC-aided stop's table (early_term = 2)
@@ -414,27 +456,69 @@ void end_timing(nrldpc_codec* h, hipStream_t s) {
     if (h->timing) { (void)hipEventRecord(h->ev1, s); h->have_time = true; }
 }
 
+// the check-node rule of a call that decodes nl rows: the handle's own (explicit cfg.alpha), or -- cfg.alpha == 0 -- the library's
+// rule for that count, on the grid nrldpc_create puts beta on
+void rule_for(const nrldpc_codec* h, int nl, float* alpha, float* beta) {
+    *alpha = h->alpha; *beta = h->beta;
+    if (!h->rule_auto || nl == h->rule_layers) return;
+    float a, b;
+    nrldpc::default_rule(h->sched.g.bg, nl, &a, &b);
+    *alpha = a;
+    *beta = std::nearbyint(2.0f * b * (float)h->scale) / (2.0f * (float)h->scale);
+}
+
+// rows a block index found by the NRLDPC_LAYERS_AUTO scans stands for: block c >= kb + 4 is row c - kb's extension column
+int layers_of_block(const nrldpc::Schedule& s, int top) { return std::max(4, top - s.g.kb + 1); }
+
+// nl: active layer count of this call (4..rows, resolved by the caller)
 nrldpc::DecArgs make_dec_args(const nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters,
-                              float* d_app, int llr_kind = -1) {
+                              float* d_app, int nl, int llr_kind = -1) {
     const nrldpc::Schedule& s = h->sched;
     nrldpc::DecArgs a;
     memset(&a, 0, sizeof a);
     a.llr = d_llr; a.hard = d_hard; a.iters = d_iters; a.app = d_app;
     a.rot = h->d_rot.p;
-    a.batch = batch; a.Z = s.Z; a.n_layers = s.n_layers; a.max_iter = h->cfg.max_iter; a.ncw = s.ncw; a.sbw = s.sbw;
+    a.batch = batch; a.Z = s.Z; a.n_layers = nl; a.max_iter = h->cfg.max_iter; a.ncw = s.ncw; a.sbw = s.sbw;
     a.early_term = h->cfg.early_term ? 1 : 0;
     if (h->cfg.early_term == 2) { a.crc_tab = h->d_crc.p; a.crc_bits = h->cfg.crc_bits; }
     a.need_ext = (a.early_term || d_app) ? 1 : 0;
     a.llr_kind = llr_kind >= 0 ? llr_kind : (h->cfg.llr_dtype == NRLDPC_LLR_F16) ? NRLDPC_K_F16 : NRLDPC_K_F32;
-    a.alpha = h->alpha; a.scale = (float)h->scale; a.inv_scale = 1.0f / (float)h->scale;
-    a.beta = h->beta * (float)h->scale;
+    float alpha, beta;
+    rule_for(h, nl, &alpha, &beta);
+    a.alpha = alpha; a.scale = (float)h->scale; a.inv_scale = 1.0f / (float)h->scale;
+    a.beta = beta * (float)h->scale;
     return a;
 }
 
-int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters, float* d_app,
-                  hipStream_t stream, int llr_kind = -1) {
+// NRLDPC_LAYERS_AUTO on device pointers, first half: the pre-pass kernel over `batch` codewords at d_llr and the copy of its
+// result into the handle's pinned word, all on `stream`; the caller synchronises the stream and calls auto_layers_read
+int auto_layers_enqueue(nrldpc_codec* h, const void* d_llr, int batch, hipStream_t stream, int llr_kind = -1) {
     const nrldpc::Schedule& s = h->sched;
-    const nrldpc::DecArgs a = make_dec_args(h, d_llr, batch, d_hard, d_iters, d_app, llr_kind);
+    HIP_TRY(h->d_best.reserve(1));
+    HIP_TRY(h->pin_best.reserve(64));
+    const int first = s.g.kb + 4, kind = llr_kind >= 0 ? llr_kind : (h->cfg.llr_dtype == NRLDPC_LLR_F16) ? NRLDPC_K_F16 : NRLDPC_K_F32;
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_best.p), first - 1, 1, stream));
+    HIP_TRY(nrldpc::launch_top_block(d_llr, kind, batch, s.Z, s.g.ncols, first, h->d_best.p, stream));
+    HIP_TRY(hipMemcpyAsync(h->pin_best.p, h->d_best.p, 4, hipMemcpyDeviceToHost, stream));
+    return NRLDPC_OK;
+}
+int auto_layers_read(const nrldpc_codec* h) { return layers_of_block(h->sched, *reinterpret_cast<const int32_t*>(h->pin_best.p)); }
+
+// the layer count of a device-pointer call: the handle's, or -- NRLDPC_LAYERS_AUTO -- read off the data (synchronises `stream`)
+int resolve_layers_dev(nrldpc_codec* h, const void* d_llr, int batch, hipStream_t stream, int* nl) {
+    if (h->layers != NRLDPC_LAYERS_AUTO) { *nl = h->layers; return NRLDPC_OK; }
+    int rc = auto_layers_enqueue(h, d_llr, batch, stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    *nl = auto_layers_read(h);
+    return NRLDPC_OK;
+}
+
+int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters, float* d_app,
+                  hipStream_t stream, int nl, int llr_kind = -1) {
+    const nrldpc::Schedule& s = h->sched;
+    const nrldpc::DecArgs a = make_dec_args(h, d_llr, batch, d_hard, d_iters, d_app, nl, llr_kind);
+    h->last_layers = nl;
     begin_timing(h, stream);
     hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, stream);
     end_timing(h, stream);
@@ -517,12 +601,12 @@ int nrldpc_create(const nrldpc_cfg* cfg_in, nrldpc_handle* out) {
     if (cfg->llr_dtype < NRLDPC_LLR_F32 || cfg->llr_dtype > NRLDPC_LLR_F64)
         return fail(NRLDPC_ERR_UNSUPPORTED, "unknown llr_dtype");
     float alpha = cfg->alpha, beta = cfg->beta;
-    if (alpha == 0.0f) { // the caller leaves the check-node rule to the library: by rate (see nrldpc_default_rule)
-        const int rows = cfg->bg == 1 ? NR_BG1_ROWS : NR_BG2_ROWS;
-        if (cfg->n_layers != 0 && (cfg->n_layers < 4 || cfg->n_layers > rows))
-            return fail(NRLDPC_ERR_UNSUPPORTED, "n_layers must be 0 or in 4..rows of the base graph");
-        nrldpc::default_rule(cfg->bg, cfg->n_layers ? cfg->n_layers : rows, &alpha, &beta);
-    }
+    const int rows = cfg->bg == 1 ? NR_BG1_ROWS : NR_BG2_ROWS;
+    if (cfg->n_layers != NRLDPC_LAYERS_ALL && cfg->n_layers != NRLDPC_LAYERS_AUTO && (cfg->n_layers < 4 || cfg->n_layers > rows))
+        return fail(NRLDPC_ERR_UNSUPPORTED, "n_layers must be 0 (all), NRLDPC_LAYERS_AUTO or in 4..rows of the base graph");
+    const int rows0 = cfg->n_layers > 0 ? cfg->n_layers : rows; // under NRLDPC_LAYERS_AUTO: until the first call says otherwise
+    if (alpha == 0.0f) // the caller leaves the check-node rule to the library: by rate (see nrldpc_default_rule)
+        nrldpc::default_rule(cfg->bg, rows0, &alpha, &beta);
     if (!(alpha > 0.0f && alpha <= 1.0f)) return fail(NRLDPC_ERR_UNSUPPORTED, "alpha must be in (0,1]");
     if (!(beta >= 0.0f && beta <= 4.0f)) return fail(NRLDPC_ERR_UNSUPPORTED, "beta must be in [0,4] LLR units");
     if (cfg->early_term < 0 || cfg->early_term > 2) return fail(NRLDPC_ERR_UNSUPPORTED, "early_term must be 0, 1 or 2");
@@ -544,9 +628,12 @@ int nrldpc_create(const nrldpc_cfg* cfg_in, nrldpc_handle* out) {
     // alpha*m - beta inside one fused multiply-add against 2^23 - beta*scale, which has to be exact
     h->beta = std::nearbyint(2.0f * beta * (float)scale) / (2.0f * (float)scale);
     h->scale = scale;
-    if (!nrldpc::build_schedule(cfg->bg, cfg->Z, cfg->n_layers, &h->sched)) {
+    h->rule_auto = cfg->alpha == 0.0f;
+    h->rule_layers = rows0;
+    h->layers = cfg->n_layers == NRLDPC_LAYERS_AUTO ? NRLDPC_LAYERS_AUTO : rows0;
+    if (!nrldpc::build_schedule(cfg->bg, cfg->Z, rows0, &h->sched)) {
         delete h;
-        return fail(NRLDPC_ERR_UNSUPPORTED, "n_layers must be 0 or in 4..rows of the base graph");
+        return fail(NRLDPC_ERR_UNSUPPORTED, "n_layers must be 0 (all), NRLDPC_LAYERS_AUTO or in 4..rows of the base graph");
     }
     if (!derive_encoder_order(h)) {
         delete h;
@@ -606,7 +693,7 @@ int nrldpc_create(const nrldpc_cfg* cfg_in, nrldpc_handle* out) {
 void nrldpc_destroy(nrldpc_handle h) {
     if (!h) return;
     DeviceScope scope(h->cfg.device_id);
-    h->d_rot.release(); h->d_crc.release();
+    h->d_rot.release(); h->d_crc.release(); h->d_best.release(); h->pin_best.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
     h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_pk.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
@@ -633,9 +720,42 @@ int nrldpc_get_dims(nrldpc_handle h, nrldpc_dims* out) {
         return fail(NRLDPC_ERR_ARG, "nrldpc_dims.struct_size does not match this library (set it to sizeof(nrldpc_dims) before the call)");
     const nrldpc::Schedule& s = h->sched;
     out->nrows = s.g.nrows; out->ncols = s.g.ncols; out->kb = s.g.kb; out->i_ls = s.ils;
-    out->K = s.g.kb * s.Z; out->N_cw = s.g.ncols * s.Z; out->n_layers = s.n_layers;
-    out->alpha = h->alpha; out->beta = h->beta;
+    out->K = s.g.kb * s.Z; out->N_cw = s.g.ncols * s.Z; out->n_layers = h->layers;
+    rule_for(h, h->layers != NRLDPC_LAYERS_AUTO ? h->layers : h->last_layers ? h->last_layers : s.g.nrows, &out->alpha, &out->beta);
     return NRLDPC_OK;
+}
+
+int nrldpc_set_layers(nrldpc_handle h, int32_t n_layers) {
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    const int rows = h->sched.g.nrows;
+    if (n_layers == NRLDPC_LAYERS_AUTO) h->layers = NRLDPC_LAYERS_AUTO;
+    else if (n_layers == NRLDPC_LAYERS_ALL) h->layers = rows;
+    else if (n_layers >= 4 && n_layers <= rows) h->layers = n_layers;
+    else return fail(NRLDPC_ERR_UNSUPPORTED, "n_layers must be 0 (all), NRLDPC_LAYERS_AUTO or in 4..rows of the base graph");
+    return NRLDPC_OK;
+}
+
+int nrldpc_set_llr_dtype(nrldpc_handle h, int32_t llr_dtype) {
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    if (llr_dtype < NRLDPC_LLR_F32 || llr_dtype > NRLDPC_LLR_F64) return fail(NRLDPC_ERR_UNSUPPORTED, "unknown llr_dtype");
+    h->cfg.llr_dtype = llr_dtype;
+    return NRLDPC_OK;
+}
+
+int nrldpc_last_layers(nrldpc_handle h, int32_t* n_layers) {
+    if (!h || !n_layers) return fail(NRLDPC_ERR_ARG, "null handle/out");
+    *n_layers = h->last_layers;
+    return NRLDPC_OK;
+}
+
+int nrldpc_count_layers(int32_t bg, int32_t Z, const void* llr, int32_t batch, int32_t llr_dtype) {
+    nrldpc::BaseGraph g;
+    if (!nrldpc::base_graph(bg, &g) || nrldpc::set_index(Z) < 0) { (void)fail(NRLDPC_ERR_UNSUPPORTED, "invalid BG / lifting size"); return -1; }
+    if (batch < 0 || (batch > 0 && !llr) || llr_dtype < NRLDPC_LLR_F32 || llr_dtype > NRLDPC_LLR_F64) { (void)fail(NRLDPC_ERR_ARG, "invalid llr / batch / llr_dtype"); return -1; }
+    const int kind = llr_dtype == NRLDPC_LLR_F64 ? NRLDPC_HQ_F64 : llr_dtype == NRLDPC_LLR_F16 ? NRLDPC_HQ_F16 : NRLDPC_HQ_F32;
+    int best = g.kb + 3;
+    nrldpc_top_block(llr, kind, (size_t)batch, 0, 1, Z, g.ncols, g.kb + 4, &best);
+    return std::max(4, best - g.kb + 1);
 }
 
 int nrldpc_set_timing(nrldpc_handle h, int32_t enabled) {
@@ -662,7 +782,10 @@ int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t
     if (h->cfg.llr_dtype == NRLDPC_LLR_F64) return fail(NRLDPC_ERR_ARG, "f64 LLRs are accepted by the host entry point only");
     if (d_app_out && h->cfg.early_term == 2) return fail(NRLDPC_ERR_UNSUPPORTED, "soft output is not available with the CRC-aided stop (early_term = 2)");
     DEVICE_SCOPE(h);
-    return decode_launch(h, d_llr, batch, d_hard, d_iters_out, d_app_out, static_cast<hipStream_t>(stream));
+    int nl = 0;
+    const int rc = resolve_layers_dev(h, d_llr, batch, static_cast<hipStream_t>(stream), &nl);
+    if (rc) return rc;
+    return decode_launch(h, d_llr, batch, d_hard, d_iters_out, d_app_out, static_cast<hipStream_t>(stream), nl);
 }
 
 int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* const* d_llr, const int32_t* batch,
@@ -694,6 +817,26 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     struct Group { std::vector<nrldpc::DecArgs> args; std::vector<int32_t> start; size_t lds = 0; int grid = 0; };
     Group g[2][2];
     std::vector<int> routed;
+    // layer count of every configuration: its handle's, or (NRLDPC_LAYERS_AUTO) read off its codewords -- all pre-pass kernels
+    // are queued first and the stream is synchronised ONCE for the lot
+    std::vector<int> nls((size_t)n, 0);
+    {
+        bool any_auto = false;
+        for (int i = 0; i < n; ++i) {
+            if (batch[i] == 0) continue;
+            if (hs[i]->layers != NRLDPC_LAYERS_AUTO) { nls[i] = hs[i]->layers; continue; }
+            for (int j = 0; j < i; ++j)
+                if (hs[j] == hs[i] && batch[j] > 0) return fail(NRLDPC_ERR_ARG, "a handle under NRLDPC_LAYERS_AUTO may appear once per nrldpc_decode_multi_dev call");
+            const int rc = auto_layers_enqueue(hs[i], d_llr[i], batch[i], st);
+            if (rc) return rc;
+            any_auto = true;
+        }
+        if (any_auto) {
+            HIP_TRY(hipStreamSynchronize(st));
+            for (int i = 0; i < n; ++i)
+                if (batch[i] > 0 && hs[i]->layers == NRLDPC_LAYERS_AUTO) nls[i] = auto_layers_read(hs[i]);
+        }
+    }
     // (Ordering the shared launches' configurations largest lifting size first -- so that the longest workgroups do not start
     // last -- was measured on BASELINE configs[3]: 0.66 ms against 0.61-0.63 ms in the caller's order, twice; not kept.)
     for (int i = 0; i < n; ++i) {
@@ -703,7 +846,8 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
         // (a handle with the CRC-aided stop always gets a launch of its own: the shared kernel is built without it)
         if (h->cfg.early_term == 2 || ((long)batch[i] * s.Z >= env_rows && nrldpc::has_z64_kernel(s.g.bg, s.Z))) { routed.push_back(i); continue; }
         Group& q = g[s.g.bg - 1][h->cfg.llr_dtype == NRLDPC_LLR_F16 ? 1 : 0];
-        q.args.push_back(make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr));
+        q.args.push_back(make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr, nls[i]));
+        h->last_layers = nls[i];
         q.start.push_back(q.grid);
         q.grid += (batch[i] + s.ncw - 1) / s.ncw;
         q.lds = std::max(q.lds, s.lds_bytes);
@@ -762,7 +906,8 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     for (size_t r = 0; r < routed.size() && rc == NRLDPC_OK; ++r) {
         const int i = routed[r];
         nrldpc_codec* h = hs[i];
-        const nrldpc::DecArgs a = make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr);
+        const nrldpc::DecArgs a = make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr, nls[i]);
+        h->last_layers = nls[i];
         hipError_t e = nrldpc::launch_decode(h->sched.g.bg, a, h->sched.threads, h->sched.lds_bytes, next_stream());
         if (e != hipSuccess) rc = hipfail(e, "decode kernel launch");
     }
@@ -789,7 +934,9 @@ namespace {
 // nrldpc_decode / nrldpc_decode_packed: `packed` = the hard decisions leave as one BIT per bit ([batch][ceil(K/8)] bytes, least
 // significant bit first) instead of one byte per bit -- packed on the device, so that an eighth of the bytes crosses PCIe and
 // goes through the copy into the caller's array
-int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out, bool packed) {
+// nl_call > 0: the layer count of this call whatever the handle says (nrldpc_pool_*: found once for the whole batch)
+int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, float* app_out, bool packed,
+                int nl_call = 0) {
     NRLDPC_API_BEGIN
     if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
@@ -824,6 +971,7 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
     const int hq_kind = f64 ? NRLDPC_HQ_F64 : h->cfg.llr_dtype == NRLDPC_LLR_F16 ? NRLDPC_HQ_F16 : NRLDPC_HQ_F32;
     const size_t host_eb = f64 ? 8 : eb; // element size of the caller's array
     static const int env_pipe = getenv("NRLDPC_HOST_PIPELINE") ? atoi(getenv("NRLDPC_HOST_PIPELINE")) : 1;
+    int nl = nl_call > 0 ? nl_call : h->layers; // NRLDPC_LAYERS_AUTO is resolved below, from the caller's array
     if (env_pipe && in_bytes >= ((size_t)8 << 20) && !app_out && !h->timing) {
         constexpr int NS = nrldpc_codec::kSlots;
         // chunk: ~NRLDPC_HOST_CHUNK_MB of wire bytes (int8 when the copy threads quantise), at least four chunks per call,
@@ -839,6 +987,14 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             h->pool = new (std::nothrow) HostPool(std::max(1, std::min(want, usable_cpus() - 1)));
             if (!h->pool) return fail(NRLDPC_ERR_NOMEM, "host thread pool");
         }
+        h->pool->follow(llr, (size_t)batch * ncw * host_eb);
+        const double t_scan0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (nl == NRLDPC_LAYERS_AUTO) // from the top column block down, on the copy threads: the all-zero blocks are read here, once
+            nl = layers_of_block(s, h->pool->top_block(llr, hq_kind, (size_t)batch, s.Z, s.g.ncols, s.g.kb + 4));
+        const double t_scan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_scan0;
+        // what no active layer reads (extension columns kb + nl ...) is neither quantised nor sent: a row goes out as its first
+        // `act` LLRs (int8 wire format only; the kernels never touch the rest of the row -- stale staging bytes at worst)
+        const size_t act = i8 ? std::min(ncw, (size_t)(s.g.kb + nl) * (size_t)s.Z) : ncw;
         for (int i = 0; i < NS; ++i) {
             HIP_TRY(h->pin_in[i].reserve((size_t)chunk * ncw * eb));
             HIP_TRY(h->pin_out[i].reserve((size_t)chunk * K));
@@ -860,7 +1016,6 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             starts.push_back(pos);
         }
         const int nchunks = (int)starts.size() - 1;
-        h->pool->follow(llr, (size_t)batch * ncw * host_eb);
         // an early error return must not leave copies or kernels of this call in flight on the two streams
         struct Quiesce {
             hipStream_t* xs; bool armed = true;
@@ -870,24 +1025,38 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
         double t_quant = 0, t_wait = 0, t_out = 0, t_enq = 0;
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         int drained = 0; // chunks 0 .. drained-1 are back in the caller's arrays
-        auto drain = [&](int k) -> int { // results of chunk k: pinned slot -> caller arrays
-            const int sl = k % NS, c0 = starts[k], n = starts[k + 1] - c0;
-            const double t0 = now();
-            HIP_TRY(hipEventSynchronize(h->xdone[sl]));
+        int cur = -1;    // the chunk whose results are on their way out, and how many of its bytes are (it may go out in pieces:
+        size_t cur_done = 0; // by the copy threads while they are idle, by this thread while they quantise the next chunk)
+        auto drain_step = [&](size_t budget, bool use_pool) -> int { // up to `budget` bytes of chunk `drained`: pinned slot -> caller array
+            const int k = drained, sl = k % NS, c0 = starts[k], n = starts[k + 1] - c0;
+            const size_t total = (size_t)n * KO;
+            if (cur != k) {
+                const double t0 = now();
+                HIP_TRY(hipEventSynchronize(h->xdone[sl]));
+                t_wait += now() - t0;
+                cur = k; cur_done = 0;
+            }
             const double t1 = now();
-            if (packed) memcpy(hard + (size_t)c0 * KO, h->pin_out[sl].p, (size_t)n * KO); // an eighth of the bytes: not worth a fan-out
-            else h->pool->move(hard + (size_t)c0 * K, h->pin_out[sl].p, (size_t)n * K, false);
-            t_wait += t1 - t0; t_out += now() - t1;
-            if (iters_out) memcpy(iters_out + c0, h->pin_it[sl].p, (size_t)n * 4);
+            const size_t len = std::min(budget, total - cur_done);
+            uint8_t* dst = hard + (size_t)c0 * KO + cur_done;
+            const char* src = h->pin_out[sl].p + cur_done;
+            if (use_pool && len >= ((size_t)1 << 20)) h->pool->move(dst, src, len, false); // (bit-packed: an eighth of the bytes, not worth a fan-out)
+            else memcpy(dst, src, len);
+            cur_done += len;
+            if (cur_done == total) {
+                if (iters_out) memcpy(iters_out + c0, h->pin_it[sl].p, (size_t)n * 4);
+                ++drained;
+            }
+            t_out += now() - t1;
             return NRLDPC_OK;
         };
+        auto ready = [&]() { return drained == cur || hipEventQuery(h->xdone[drained % NS]) == hipSuccess; };
         for (int k = 0; k < nchunks; ++k) {
             const int sl = k % NS, st = k & 1, c0 = starts[k], n = starts[k + 1] - c0;
             // the slot's previous chunk has to be out (that also frees pin_in[sl]); chunks that happen to be finished
-            // are taken out now rather than in one lump at the end
-            while (drained <= k - NS || (drained < k && hipEventQuery(h->xdone[drained % NS]) == hipSuccess)) {
-                int rc = drain(drained); if (rc) return rc;
-                ++drained;
+            // are taken out now (the copy threads are idle) rather than in one lump at the end
+            while (drained <= k - NS || (drained < k && ready())) {
+                int rc = drain_step((size_t)-1, true); if (rc) return rc;
             }
             const size_t off = (size_t)c0 * ncw;
             char* d_in = h->s_llr.p + off * eb;
@@ -899,18 +1068,31 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             if (i8) {
                 int8_t* d_q = h->s_q.p + q_slot * sl;
                 int8_t* pin = reinterpret_cast<int8_t*>(h->pin_in[sl].p);
-                const size_t total = (size_t)n * ncw;
+                const size_t total = (size_t)n * act; // compact: [n][act]
                 const int parts = (k == 0 && total >= ((size_t)1 << 20)) ? 4 : 1;
+                bool sent = false;
                 for (int pi = 0; pi < parts && as_i8; ++pi) {
                     const size_t lo = (total * pi / parts) & ~(size_t)63, hi = pi + 1 == parts ? total : ((total * (pi + 1) / parts) & ~(size_t)63);
-                    if (h->pool->quantise(pin + lo, static_cast<const char*>(llr) + (off + lo) * host_eb, hi - lo, hq_kind, (float)h->scale))
+                    h->pool->quantise_rows_start(pin, static_cast<const char*>(llr) + off * host_eb, act, ncw, lo, hi, hq_kind, (float)h->scale);
+                    // while the copy threads quantise, this thread takes finished chunks' results out, a piece at a time (round 4
+                    // ran the two one after the other; with MATLAB doubles the copy threads are the longest phase of a call)
+                    while (!h->pool->done() && drained < k && ready()) {
+                        int rc = drain_step((size_t)256 << 10, false);
+                        if (rc) { (void)h->pool->quantise_rows_finish(); return rc; }
+                    }
+                    if (h->pool->quantise_rows_finish()) {
                         as_i8 = false; // a -inf: int8 has no code for it (pieces already sent are simply not used)
-                    else
+                    } else {
                         HIP_TRY(hipMemcpyAsync(d_q + lo, pin + lo, hi - lo, hipMemcpyHostToDevice, h->xs[st]));
+                        sent = true;
+                    }
                 }
                 if (as_i8) {
                     kind = NRLDPC_K_F16; // whatever the handle's format: this chunk reaches the decoder as fp16
-                    HIP_TRY(nrldpc::launch_expand_i8(d_q, d_in, total, 1.0f / (float)h->scale, h->xs[st]));
+                    HIP_TRY(nrldpc::launch_expand_i8_rows(d_q, d_in, (size_t)n, act, ncw, 1.0f / (float)h->scale, h->xs[st]));
+                } else if (sent) {
+                    // the pieces already queued still read this pinned slot, which the fallback below overwrites
+                    HIP_TRY(hipStreamSynchronize(h->xs[st]));
                 }
             }
             if (!as_i8) { // the handle's own format (NRLDPC_HOST_I8=0, or a chunk that holds a -inf)
@@ -919,7 +1101,7 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
                 HIP_TRY(hipMemcpyAsync(d_in, h->pin_in[sl].p, (size_t)n * ncw * eb, hipMemcpyHostToDevice, h->xs[st]));
             }
             const double tq1 = now();
-            int rc = decode_launch(h, d_in, n, h->s_hard.p + (size_t)c0 * K, iters_out ? h->s_iters.p + c0 : nullptr, nullptr, h->xs[st], kind);
+            int rc = decode_launch(h, d_in, n, h->s_hard.p + (size_t)c0 * K, iters_out ? h->s_iters.p + c0 : nullptr, nullptr, h->xs[st], nl, kind);
             if (rc) return rc;
             t_quant += tq1 - tq0; t_enq -= tq1;
             if (packed) {
@@ -932,14 +1114,19 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             HIP_TRY(hipEventRecord(h->xdone[sl], h->xs[st]));
             t_enq += now();
         }
-        for (; drained < nchunks; ++drained) { int rc = drain(drained); if (rc) return rc; }
+        while (drained < nchunks) { int rc = drain_step((size_t)-1, true); if (rc) return rc; }
         if (trace)
-            fprintf(stderr, "[nrldpc host path] %d chunks of %d: copy/quantise in %.2f ms (incl. H2D enqueue), launch+D2H enqueue %.2f, wait for device %.2f, copy out %.2f; copy threads on NUMA node %d (caller on CPU %d)\n",
-                    nchunks, chunk, t_quant, t_enq, t_wait, t_out, h->pool->node_, sched_getcpu());
+            fprintf(stderr, "[nrldpc host path] %d chunks of %d, %d layers (%zu of %zu LLRs per codeword on the wire; scan %.2f ms): copy/quantise in %.2f ms (incl. H2D enqueue), launch+D2H enqueue %.2f, wait for device %.2f, copy out %.2f; copy threads on NUMA node %d (caller on CPU %d)\n",
+                    nchunks, chunk, nl, act, ncw, t_scan, t_quant, t_enq, t_wait, t_out, h->pool->node_, sched_getcpu());
         quiesce.armed = false; // every chunk was drained behind its event
         return NRLDPC_OK;
     }
 
+    if (nl == NRLDPC_LAYERS_AUTO) { // a small batch: the caller's thread scans it
+        int best = s.g.kb + 3;
+        nrldpc_top_block(llr, hq_kind, (size_t)batch, 0, 1, s.Z, s.g.ncols, s.g.kb + 4, &best);
+        nl = layers_of_block(s, best);
+    }
     const void* src = llr;
     if (f64) { // MATLAB doubles: narrow on the host (halves PCIe bytes)
         h->h_narrow.resize((size_t)batch * ncw);
@@ -950,7 +1137,7 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
     HIP_TRY(hipMemcpyAsync(h->s_llr.p, src, (size_t)batch * ncw * eb, hipMemcpyHostToDevice, nullptr));
     // F64 was narrowed to f32 above; the kernel sees f32 in that case.
     int rc = decode_launch(h, h->s_llr.p, batch, h->s_hard.p, iters_out ? h->s_iters.p : nullptr,
-                           app_out ? h->s_app.p : nullptr, nullptr);
+                           app_out ? h->s_app.p : nullptr, nullptr, nl);
     if (rc) return rc;
     if (packed) {
         HIP_TRY(nrldpc::launch_pack_bits(h->s_hard.p, h->s_pk.p, batch, (int)K, nullptr));
@@ -992,6 +1179,12 @@ struct nrldpc_pool {
     bool stop = false;
     const char* llr = nullptr; uint8_t* hard = nullptr; int32_t* iters = nullptr;
     int batch = 0, chunk = 0, nchunks = 0, next = 0, running = 0, rc = NRLDPC_OK;
+    bool packed = false; // hard decisions leave bit-packed (nrldpc_pool_decode_packed)
+    int layers = 0;      // as nrldpc_codec::layers (nrldpc_pool_set_layers); nl_call: what this call runs with
+    int nl_call = 0;
+    // NRLDPC_LAYERS_AUTO, device form: every shard scans its slice, the last one to arrive takes the maximum, all launch with it
+    int scan_arrived = 0, scan_best = 0;
+    std::condition_variable cv_scan;
     std::string err;
     // device-resident job (nrldpc_pool_decode_dev): shard i launches on its own stream and waits for it
     bool dev_job = false;
@@ -1008,9 +1201,24 @@ struct nrldpc_pool {
         // everything already submitted to this device (whatever stream produced d_llr[i]) before the launch.  The call is
         // synchronous anyway -- it returns when every shard is done -- so this costs no overlap the caller could have had.
         HIP_TRY(hipDeviceSynchronize());
-        const int r = nrldpc_decode_dev(h, dv_llr[i], dv_batch[i], dv_hard[i], dv_iters ? dv_iters[i] : nullptr, nullptr, streams[i]);
+        if (h->cfg.llr_dtype == NRLDPC_LLR_F64) return fail(NRLDPC_ERR_ARG, "f64 LLRs are accepted by the host entry point only");
+        const int r = decode_launch(h, dv_llr[i], dv_batch[i], dv_hard[i], dv_iters ? dv_iters[i] : nullptr, nullptr, streams[i], nl_call);
         if (r != NRLDPC_OK) return r;
         HIP_TRY(hipStreamSynchronize(streams[i]));
+        return NRLDPC_OK;
+    }
+    // first phase of a device-form call under NRLDPC_LAYERS_AUTO: this shard's highest non-zero column block (first - 1: none)
+    int scan_dev_shard(int i, int* top) {
+        nrldpc_handle h = hs[i];
+        *top = h->sched.g.kb + 3;
+        if (dv_batch[i] <= 0 || h->cfg.llr_dtype == NRLDPC_LLR_F64) return NRLDPC_OK; // (errors are reported by the decode phase)
+        DEVICE_SCOPE(h);
+        if (!streams[i]) HIP_TRY(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));
+        HIP_TRY(hipDeviceSynchronize());
+        const int r = auto_layers_enqueue(h, dv_llr[i], dv_batch[i], streams[i]);
+        if (r != NRLDPC_OK) return r;
+        HIP_TRY(hipStreamSynchronize(streams[i]));
+        *top = *reinterpret_cast<const int32_t*>(h->pin_best.p);
         return NRLDPC_OK;
     }
 
@@ -1024,6 +1232,24 @@ struct nrldpc_pool {
                 seen = gen;
             }
             if (dev_job) {
+                if (layers == NRLDPC_LAYERS_AUTO) {
+                    int top = 0;
+                    const int rs = scan_dev_shard(i, &top);
+                    std::unique_lock<std::mutex> lk(m);
+                    if (rs != NRLDPC_OK && rc == NRLDPC_OK) { rc = rs; err = nrldpc_last_error(); }
+                    scan_best = std::max(scan_best, top);
+                    if (++scan_arrived == (int)hs.size()) {
+                        nl_call = layers_of_block(hs[0]->sched, scan_best);
+                        cv_scan.notify_all();
+                    } else {
+                        cv_scan.wait(lk, [&] { return scan_arrived == (int)hs.size(); });
+                    }
+                    if (rc != NRLDPC_OK) { // some shard's scan failed: nobody launches
+                        split[i] = 0;
+                        if (--running == 0) cv_done.notify_all();
+                        continue;
+                    }
+                }
                 const int r = decode_dev_shard(i);
                 std::lock_guard<std::mutex> lk(m);
                 if (r != NRLDPC_OK && rc == NRLDPC_OK) { rc = r; err = nrldpc_last_error(); }
@@ -1036,8 +1262,8 @@ struct nrldpc_pool {
                     k = next++;
                 }
                 const int c0 = k * chunk, n = std::min(chunk, batch - c0);
-                const int r = nrldpc_decode(hs[i], llr + (size_t)c0 * ncw * eb, n, hard + (size_t)c0 * K,
-                                            iters ? iters + c0 : nullptr, nullptr);
+                const int r = decode_host(hs[i], llr + (size_t)c0 * ncw * eb, n, hard + (size_t)c0 * (packed ? (K + 7) / 8 : K),
+                                          iters ? iters + c0 : nullptr, nullptr, packed, nl_call);
                 std::lock_guard<std::mutex> lk(m);
                 if (r != NRLDPC_OK && rc == NRLDPC_OK) { rc = r; err = nrldpc_last_error(); }
                 split[i] += n;
@@ -1078,6 +1304,7 @@ int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t
     const nrldpc::Schedule& s = p->hs[0]->sched;
     p->ncw = (size_t)s.g.ncols * s.Z; p->K = (size_t)s.g.kb * s.Z;
     p->eb = cfg->llr_dtype == NRLDPC_LLR_F64 ? 8 : cfg->llr_dtype == NRLDPC_LLR_F16 ? 2 : 4; // in the caller's array
+    p->layers = p->hs[0]->layers;
     p->split.assign(n_devices, 0);
     p->streams.assign(n_devices, nullptr);
     for (int i = 0; i < n_devices; ++i) p->th.emplace_back([p, i] { p->worker(i); });
@@ -1086,13 +1313,29 @@ int nrldpc_pool_create(const nrldpc_cfg* cfg, const int32_t* device_ids, int32_t
     NRLDPC_API_END
 }
 
-int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out) {
+} // extern "C"
+namespace {
+int pool_decode_host(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out, bool packed) {
     NRLDPC_API_BEGIN
     if (!p) return fail(NRLDPC_ERR_ARG, "null pool");
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");
     if (batch == 0) return NRLDPC_OK;
     if (!llr || !hard) return fail(NRLDPC_ERR_ARG, "null llr/hard pointer");
     std::unique_lock<std::mutex> lk(p->m);
+    p->packed = packed;
+    p->nl_call = p->layers;
+    if (p->layers == NRLDPC_LAYERS_AUTO) { // once for the whole batch, before it is cut: a few short-lived threads over the caller's array
+        const nrldpc::Schedule& s = p->hs[0]->sched;
+        const int kind = p->eb == 8 ? NRLDPC_HQ_F64 : p->eb == 2 ? NRLDPC_HQ_F16 : NRLDPC_HQ_F32;
+        const int nt = std::max(1, std::min({8, usable_cpus(), batch}));
+        int best = s.g.kb + 3;
+        std::vector<std::thread> ts;
+        for (int t = 1; t < nt; ++t)
+            ts.emplace_back([&, t] { nrldpc_top_block(llr, kind, (size_t)batch, (size_t)t, (size_t)nt, s.Z, s.g.ncols, s.g.kb + 4, &best); });
+        nrldpc_top_block(llr, kind, (size_t)batch, 0, (size_t)nt, s.Z, s.g.ncols, s.g.kb + 4, &best);
+        for (auto& t : ts) t.join();
+        p->nl_call = layers_of_block(s, best);
+    }
     const int want = (int)p->hs.size() * p->chunks_per_device;
     p->chunk = std::max(1, (batch + want - 1) / want);
     p->nchunks = (batch + p->chunk - 1) / p->chunk;
@@ -1108,6 +1351,26 @@ int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uin
     return NRLDPC_OK;
     NRLDPC_API_END
 }
+} // namespace
+extern "C" {
+
+int nrldpc_pool_decode(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard, int32_t* iters_out) {
+    return pool_decode_host(p, llr, batch, hard, iters_out, false);
+}
+int nrldpc_pool_decode_packed(nrldpc_pool_handle p, const void* llr, int32_t batch, uint8_t* hard_packed, int32_t* iters_out) {
+    return pool_decode_host(p, llr, batch, hard_packed, iters_out, true);
+}
+
+int nrldpc_pool_set_layers(nrldpc_pool_handle p, int32_t n_layers) {
+    if (!p) return fail(NRLDPC_ERR_ARG, "null pool");
+    std::lock_guard<std::mutex> lk(p->m);
+    for (auto h : p->hs) {
+        const int rc = nrldpc_set_layers(h, n_layers);
+        if (rc != NRLDPC_OK) return rc;
+    }
+    p->layers = p->hs[0]->layers;
+    return NRLDPC_OK;
+}
 
 int nrldpc_pool_decode_dev(nrldpc_pool_handle p, const void* const* d_llr, const int32_t* batch, uint8_t* const* d_hard,
                            int32_t* const* d_iters) {
@@ -1118,6 +1381,7 @@ int nrldpc_pool_decode_dev(nrldpc_pool_handle p, const void* const* d_llr, const
         if (batch[i] > 0 && (!d_llr[i] || !d_hard[i])) return fail(NRLDPC_ERR_ARG, "null device pointer for a shard with work");
     std::unique_lock<std::mutex> lk(p->m);
     p->dev_job = true;
+    p->nl_call = p->layers; p->scan_arrived = 0; p->scan_best = 0;
     p->dv_llr = d_llr; p->dv_batch = batch; p->dv_hard = d_hard; p->dv_iters = d_iters;
     p->rc = NRLDPC_OK; p->err.clear();
     std::fill(p->split.begin(), p->split.end(), 0);

@@ -210,10 +210,14 @@ __device__ __forceinline__ void decode_body(const DecArgs& a, const int32_t* __r
         });
         if (a.early_term) {
             if (tid <= a.ncw) flags[tid] = 0; // flags[ncw] = "some codeword of this workgroup still fails"
-            // CRC-aided stop (early_term = 2): per codeword CRC_SLOTS words behind the flags (16-byte aligned)
-            int* crc_slots = flags + ((a.ncw + 1 + 3) & ~3) + cwl * CRC_SLOTS;
+            // CRC-aided stop (early_term = 2): per codeword CRC_SLOTS words behind the flags, at the next 16-byte boundary of LDS --
+            // the flags themselves sit at Z*sbw, only a multiple of 4 when Z*ncw is odd (BG2 Z = 7 ...), and crc_holds() reads the
+            // slots as int4 (nrldpc_create leaves 16 bytes of slack for this)
+            const uint32_t slots_off = (uint32_t)(((size_t)Z * a.sbw + 4 * (size_t)(a.ncw + 1) + 15) & ~(size_t)15);
+            int* crc_base = reinterpret_cast<int*>(lds + slots_off);
+            int* crc_slots = crc_base + cwl * CRC_SLOTS;
             if constexpr (CRC)
-                for (int i = tid; i < a.ncw * CRC_SLOTS; i += (int)blockDim.x) flags[((a.ncw + 1 + 3) & ~3) + i] = 0;
+                for (int i = tid; i < a.ncw * CRC_SLOTS; i += (int)blockDim.x) crc_base[i] = 0;
             __syncthreads();
             if (CRC && !done) { // every thread folds the information bits at its own ring position z of each column
                 CrcFold f;

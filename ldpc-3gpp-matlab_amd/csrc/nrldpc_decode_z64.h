@@ -27,6 +27,15 @@
 #define NRLDPC_DECODE_Z64_H
 #include "nrldpc_device.h"
 
+// Everything in this header and in nrldpc_decode_z64s.h / _z64p.h depends on the -D flags of the translation unit that includes it
+// (NRLDPC_Z64_PACK, NRLDPC_Z64_ILV, NRLDPC_Z64S_DUAL, ...: Z64<1, 256> is the block geometry of Z = 256 in one unit and four interleaved
+// codewords of Z = 64 in another), so the same template names would mean different things in different units of one library -- a
+// violation of the one-definition rule that only inlining hid.  Each unit therefore puts these headers' contents into an
+// inline name space of its own, named by build.py after the unit's object file: distinct symbols, same spelling at the point of use.
+#ifndef NRLDPC_UNIT
+#define NRLDPC_UNIT u_default
+#endif
+
 // scheduling experiments of the software pipeline (see pipeline_z64 / LayerZ64::track3); 0 = the shipped schedule
 #ifndef NRLDPC_Z64_POSTBAR
 #define NRLDPC_Z64_POSTBAR 0
@@ -51,6 +60,7 @@
 #endif
 
 namespace nrldpc {
+inline namespace NRLDPC_UNIT { // one name space per translation unit: see NRLDPC_UNIT in nrldpc_decode_z64.h
 
 template <int T> __device__ __forceinline__ bool lane_ge() {
     static_assert(T >= 1 && T <= 63, "a proper subset of the wave");
@@ -1024,9 +1034,14 @@ __global__ __launch_bounds__(NCWG * z64_nwv(ZC) * 64, (z64_wpe<BG, ZC, NCWG, NL>
     int my_iters = a.max_iter;
     // violated-check vote of one codeword's waves -> flags; returns after the closing barrier
     auto parity_pass = [&](int it) {
+        static_assert(G::BLK == 64 || G::NCWG + 1 <= G::BLK, "flags are cleared by raw thread id: lanes >= BLK have retired");
         if (tid <= G::NCWG) flags[tid] = 0;
         int* crc_slots = flags + G::FLAG_BYTES / 4 + cwl * CRC_SLOTS; // CRC-aided stop (early_term = 2)
-        if constexpr (CRC) { if (tid < G::NCWG * CRC_SLOTS) flags[G::FLAG_BYTES / 4 + tid] = 0; }
+        if constexpr (CRC) {
+            // by the DENSE index of the lanes that are still here: lanes >= BLK of every wave returned at entry, so a raw thread
+            // id skips words (BG2 Z = 144: BLK 48, four codewords -> 80 words, tids 48..63 absent)
+            for (int i = wave * G::BLK + lane; i < G::NCWG * CRC_SLOTS; i += G::NCWG * G::NWV * G::BLK) flags[G::FLAG_BYTES / 4 + i] = 0;
+        }
         __syncthreads();
         if (CRC && !done) { // the information bits at this thread's own ring position z of every column (primary copy:
             CrcFold f;             // a column's last writer of an iteration leaves both copies fresh)
@@ -1214,9 +1229,11 @@ static hipError_t launch_z64f(const DecArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+} // inline namespace NRLDPC_UNIT
 } // namespace nrldpc
 #include "nrldpc_decode_z64s.h" // the two-threads-per-row form of the same decoder
 namespace nrldpc {
+inline namespace NRLDPC_UNIT { // one name space per translation unit: see NRLDPC_UNIT in nrldpc_decode_z64.h
 
 // Which form serves a (BG, Z, layer count): the measured choice, z64_split_default -- both forms timed on the MI355X for
 // every pair at 25 fixed iterations and with the parity-check stop, in one session (tools/bench_forms.py,
@@ -1322,5 +1339,6 @@ template <int BG, int ZC, int NCWG> static hipError_t launch_z64(const DecArgs& 
     return hipErrorUnknown; // not reached
 }
 
+} // inline namespace NRLDPC_UNIT
 } // namespace nrldpc
 #endif

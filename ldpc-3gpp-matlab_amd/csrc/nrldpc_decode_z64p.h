@@ -13,6 +13,7 @@
 #include "nrldpc_decode_z64.h"
 
 namespace nrldpc {
+inline namespace NRLDPC_UNIT { // one name space per translation unit: see NRLDPC_UNIT in nrldpc_decode_z64.h
 
 template <int BG, int ZC, int NL = BGT<BG>::ROWS> struct Z64P : Z64<BG, ZC, 1, NL> {
     using B = Z64<BG, ZC, 1, NL>;
@@ -237,6 +238,8 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
             if constexpr (ETP) {
                 // parity check of this half's rows, per codeword: flags[c] = "codeword c has a violated check",
                 // flags[NCW] = "a codeword that had not converged before still has one"
+                // (raw thread ids: the lanes >= BLK of a wave have retired, so the NCW + 1 flags must fit below BLK)
+                static_assert(!G::ILVM || G::BLK == 64 || G::NCW + 1 <= G::BLK, "flags are cleared by raw thread id: lanes >= BLK have retired");
                 if ((int)threadIdx.x <= G::NCW) flags[threadIdx.x] = 0;
                 __syncthreads();
                 const int c = where().c; // (this shadows the prologue's copy on purpose: see `where`)
@@ -550,5 +553,6 @@ template <int BG, int ZC> static hipError_t launch_z64p(const DecArgs& a, hipStr
     else return launch_z64p_t<BG, ZC, true>(a, s);
 }
 
+} // inline namespace NRLDPC_UNIT
 } // namespace nrldpc
 #endif

@@ -22,6 +22,7 @@
 #include "nrldpc_decode_z64.h"
 
 namespace nrldpc {
+inline namespace NRLDPC_UNIT { // one name space per translation unit: see NRLDPC_UNIT in nrldpc_decode_z64.h
 
 #ifndef NRLDPC_Z64S_WPE
 #define NRLDPC_Z64S_WPE 6 // waves per SIMD the register allocation is sized for (two 12-wave workgroups per CU at Z = 384)
@@ -478,5 +479,6 @@ template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS, bool CRC = false> st
     return hipGetLastError();
 }
 
+} // inline namespace NRLDPC_UNIT
 } // namespace nrldpc
 #endif

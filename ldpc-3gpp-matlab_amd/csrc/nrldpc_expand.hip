@@ -55,6 +55,47 @@ hipError_t launch_expand_i8(const int8_t* d_q, void* d_out_f16, size_t n, float 
     return hipGetLastError();
 }
 
+// The same for a chunk whose rows were sent COMPACT: n_rows rows of `act` int8 each -> the first act LLRs of rows that are `pitch`
+// fp16 apart (what follows in a row -- extension columns no active layer reads, nrldpc.h "Active layers" -- is left as it is).
+__global__ __launch_bounds__(256) void nrldpc_expand_i8_rows_kernel(const int8_t* __restrict__ q, __half* __restrict__ out, unsigned n_rows,
+                                                                    unsigned act, unsigned pitch, float inv_scale, int vec) {
+    const unsigned total = n_rows * act;
+    if (vec) { // act % 16 == 0, pitch % 8 == 0, both bases 16-byte aligned: 16 LLRs per thread and trip, never across a row end
+        const unsigned nv = total >> 4;
+        const uint4* q4 = reinterpret_cast<const uint4*>(q);
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+            const unsigned e = i << 4, r = e / act, c = e - r * act;
+            const uint4 v = q4[i];
+            uint4 lo, hi;
+            lo.x = expand_pair(v.x, 0, inv_scale); lo.y = expand_pair(v.x, 16, inv_scale);
+            lo.z = expand_pair(v.y, 0, inv_scale); lo.w = expand_pair(v.y, 16, inv_scale);
+            hi.x = expand_pair(v.z, 0, inv_scale); hi.y = expand_pair(v.z, 16, inv_scale);
+            hi.z = expand_pair(v.w, 0, inv_scale); hi.w = expand_pair(v.w, 16, inv_scale);
+            uint4* o4 = reinterpret_cast<uint4*>(out + (size_t)r * pitch + c);
+            o4[0] = lo; o4[1] = hi;
+        }
+        return;
+    }
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / act, c = i - r * act;
+        const int a = (int)q[i];
+        out[(size_t)r * pitch + c] = a == -128 ? __ushort_as_half((unsigned short)0x7C00u) : __float2half((float)a * inv_scale);
+    }
+}
+
+hipError_t launch_expand_i8_rows(const int8_t* d_q, void* d_out_f16, size_t n_rows, size_t act, size_t pitch, float inv_scale,
+                                 hipStream_t stream) {
+    if (n_rows == 0 || act == 0) return hipSuccess;
+    if (act == pitch) return launch_expand_i8(d_q, d_out_f16, n_rows * act, inv_scale, stream);
+    if (n_rows * act >= ((size_t)1 << 32)) return hipErrorInvalidValue; // chunks are tens of megabytes
+    const int vec = (act % 16 == 0) && (pitch % 8 == 0) && ((reinterpret_cast<uintptr_t>(d_q) | reinterpret_cast<uintptr_t>(d_out_f16)) & 15) == 0;
+    const size_t want = ((vec ? (n_rows * act) >> 4 : n_rows * act) + 255) / 256;
+    const int grid = (int)(want < 1 ? 1 : want > 8192 ? 8192 : want);
+    hipLaunchKernelGGL(nrldpc_expand_i8_rows_kernel, dim3(grid), dim3(256), 0, stream, d_q, static_cast<__half*>(d_out_f16), (unsigned)n_rows,
+                       (unsigned)act, (unsigned)pitch, inv_scale, vec);
+    return hipGetLastError();
+}
+
 // ---- hard decisions, one byte per bit -> one bit per bit (nrldpc_decode_packed: 8x fewer bytes over PCIe and through the
 // caller's copy).  One thread per output byte; rows whose length and address allow it read their eight input bytes as one
 // 64-bit word and gather the bits with one multiply (bytes are 0 / 1: byte j lands on bit 56 + j, no carries meet).
@@ -85,6 +126,47 @@ hipError_t launch_pack_bits(const uint8_t* d_hard, uint8_t* d_packed, int rows, 
     const size_t want = ((size_t)rows * KB8 + 255) / 256;
     const int grid = (int)(want > 16384 ? 16384 : want);
     hipLaunchKernelGGL(nrldpc_pack_bits_kernel, dim3(grid), dim3(256), 0, stream, d_hard, d_packed, rows, K, KB8, wide);
+    return hipGetLastError();
+}
+
+// ---- NRLDPC_LAYERS_AUTO on device-resident LLRs: highest column block holding anything but +-0 / NaN (nrldpc_hostpath.h)
+template <int DT>
+__global__ __launch_bounds__(256) void nrldpc_top_block_kernel(const void* __restrict__ llr, int batch, int Z, int nblocks, int first,
+                                                               int* __restrict__ best) {
+    const int lane = threadIdx.x & 63;
+    const long long nitems = (long long)(nblocks - first) * batch; // item = rank * batch + codeword, rank 0 = the top block
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long it = wave0; it < nitems; it += nwaves) {
+        const int b = nblocks - 1 - (int)(it / batch);
+        const int cw = (int)(it % batch);
+        if (b <= __atomic_load_n(best, __ATOMIC_RELAXED)) return; // every later item of this wave is in the same or a lower block
+        const size_t base = ((size_t)cw * nblocks + (size_t)b) * (size_t)Z;
+        bool hit = false;
+        for (int i = lane; i < Z; i += 64) {
+            if constexpr (DT == NRLDPC_K_F16) {
+                const unsigned a = static_cast<const unsigned short*>(llr)[base + i] & 0x7fffu;
+                hit |= (a != 0u) & (a <= 0x7c00u);
+            } else {
+                const unsigned a = static_cast<const unsigned*>(llr)[base + i] & 0x7fffffffu;
+                hit |= (a != 0u) & (a <= 0x7f800000u);
+            }
+        }
+        if (__any((int)hit)) {
+            if (lane == 0) atomicMax(best, b);
+            return; // anything this wave would look at next is not above b
+        }
+    }
+}
+
+hipError_t launch_top_block(const void* d_llr, int llr_kind, int batch, int Z, int nblocks, int first, int* d_best, hipStream_t stream) {
+    if (batch <= 0 || nblocks <= first) return hipSuccess;
+    const long long nitems = (long long)(nblocks - first) * batch;
+    const long long want = (nitems + 3) / 4;
+    const int grid = (int)(want > 4096 ? 4096 : want);
+    if (llr_kind == NRLDPC_K_F16)
+        hipLaunchKernelGGL(nrldpc_top_block_kernel<NRLDPC_K_F16>, dim3(grid), dim3(256), 0, stream, d_llr, batch, Z, nblocks, first, d_best);
+    else
+        hipLaunchKernelGGL(nrldpc_top_block_kernel<NRLDPC_K_F32>, dim3(grid), dim3(256), 0, stream, d_llr, batch, Z, nblocks, first, d_best);
     return hipGetLastError();
 }
 

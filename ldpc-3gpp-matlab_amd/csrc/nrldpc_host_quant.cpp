@@ -130,6 +130,55 @@ template <int KIND> bool quant(int8_t* dst, const void* src, size_t n, float sca
 
 } // namespace
 
+// ---- NRLDPC_LAYERS_AUTO: "is there anything but +-0 and NaN in this block" on the raw bits (integer compares vectorise for every
+// element type: |x| != 0 and |x| <= inf)
+namespace {
+template <class U> struct Bits;
+template <> struct Bits<uint16_t> { static constexpr uint16_t ABS = 0x7fffu, INF = 0x7c00u; };
+template <> struct Bits<uint32_t> { static constexpr uint32_t ABS = 0x7fffffffu, INF = 0x7f800000u; };
+template <> struct Bits<uint64_t> { static constexpr uint64_t ABS = 0x7fffffffffffffffull, INF = 0x7ff0000000000000ull; };
+template <class U> bool any_set(const U* p, size_t n) {
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        unsigned acc = 0;
+        for (int k = 0; k < 64; ++k) {
+            const U a = (U)(p[i + k] & Bits<U>::ABS);
+            acc |= (unsigned)((a != 0) & (a <= Bits<U>::INF));
+        }
+        if (acc) return true;
+    }
+    for (; i < n; ++i) {
+        const U a = (U)(p[i] & Bits<U>::ABS);
+        if (a != 0 && a <= Bits<U>::INF) return true;
+    }
+    return false;
+}
+template <class U> void top_block(const U* src, size_t n_total, size_t cw0, size_t cw_step, int Z, int nblocks, int first, int* best) {
+    for (size_t cw = cw0; cw < n_total; cw += cw_step) {
+        const U* base = src + cw * (size_t)nblocks * (size_t)Z;
+        for (int b = nblocks - 1; b >= first; --b) {
+            if (b <= __atomic_load_n(best, __ATOMIC_RELAXED)) break;
+            if (any_set(base + (size_t)b * Z, (size_t)Z)) {
+                int cur = __atomic_load_n(best, __ATOMIC_RELAXED);
+                while (cur < b && !__atomic_compare_exchange_n(best, &cur, b, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                break;
+            }
+        }
+        if (__atomic_load_n(best, __ATOMIC_RELAXED) >= nblocks - 1) return;
+    }
+}
+} // namespace
+
+void nrldpc_top_block(const void* src, int src_kind, size_t n_total, size_t cw0, size_t cw_step, int Z, int nblocks, int first,
+                      int* best) {
+    if (cw_step == 0) cw_step = 1;
+    switch (src_kind) {
+        case NRLDPC_HQ_F16: top_block(static_cast<const uint16_t*>(src), n_total, cw0, cw_step, Z, nblocks, first, best); break;
+        case NRLDPC_HQ_F64: top_block(static_cast<const uint64_t*>(src), n_total, cw0, cw_step, Z, nblocks, first, best); break;
+        default: top_block(static_cast<const uint32_t*>(src), n_total, cw0, cw_step, Z, nblocks, first, best); break;
+    }
+}
+
 bool nrldpc_quantise_i8_path(int8_t* dst, const void* src, size_t n, int src_kind, float scale, int path) {
     switch (src_kind) {
         case NRLDPC_HQ_F16: return quant<NRLDPC_HQ_F16>(dst, src, n, scale, path);

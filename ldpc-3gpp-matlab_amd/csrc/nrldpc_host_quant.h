@@ -18,4 +18,11 @@ bool nrldpc_quantise_i8(int8_t* dst, const void* src, size_t n, int src_kind, fl
 // falling back to the next one down when the CPU lacks it (tests compare the paths with each other)
 bool nrldpc_quantise_i8_path(int8_t* dst, const void* src, size_t n, int src_kind, float scale, int path);
 
+// Highest block b in [first, nblocks) -- a block = Z consecutive values, a codeword = nblocks blocks -- in which any of the n_cw
+// codewords [cw0, cw0 + cw_step, ...) < n_total at src holds a value other than +-0 and NaN; first - 1 when there is none.
+// NRLDPC_LAYERS_AUTO's scan (nrldpc.h "Active layers"): from the top block down, per codeword, never below *best + 1 -- `best`
+// is shared by the threads that scan one call (relaxed atomic maximum; start it at first - 1).
+void nrldpc_top_block(const void* src, int src_kind, size_t n_total, size_t cw0, size_t cw_step, int Z, int nblocks, int first,
+                      int* best);
+
 #endif

@@ -32,6 +32,9 @@ class NRLDPCDecoder(NRLDPC):
     _TUNABLE = NRLDPC._TUNABLE + ("iterations",)
 
     def __init__(self, device_id=0, alpha=None, llr_scale=0, prune_layers=True, beta=0.0, crc_stop=False, **kw):
+        """prune_layers: True = the active rows from the object's parameters (active_layers(), kept at the maximum seen while
+        HARQ state is pending); "auto" = NRLDPC_LAYERS_AUTO, read off every step's LLRs by the library (what the MEX gateway
+        does: it sees cw_tilde only, NRLDPCDecoder.m:265); False = every row, as the reference."""
         self._I_HARQ = 0        # NRLDPCDecoder.m:34
         self._iterations = 50   # NRLDPCDecoder.m:41
         super().__init__(**kw)
@@ -63,12 +66,16 @@ class NRLDPCDecoder(NRLDPC):
 
     # -- System-object protocol ------------------------------------------------------------------
     def _make_codec(self, n_layers):
-        if self._codec is not None:
-            self._codec.close()
-        self._codec = Codec(self.BG, self.Z_c, max_iter=self._setup_iterations, n_layers=n_layers,
-                            early_term=True, alpha=self._alpha or 0.0, beta=self._beta, llr_scale=self._llr_scale,
-                            llr_dtype=np.float32, device_id=self._device_id,
-                            crc=self.code_block_check() if self._crc_stop else None)
+        """One codec for the object's lifetime (setupImpl, NRLDPCDecoder.m:120); the active layer count is a property of the
+        call (nrldpc_set_layers, ABI revision 5): a change of rate between steps -- G and rv_id are tunable, NRLDPC.m:51-85 --
+        costs no device work."""
+        if self._codec is None:
+            self._codec = Codec(self.BG, self.Z_c, max_iter=self._setup_iterations, n_layers=n_layers,
+                                early_term=True, alpha=self._alpha or 0.0, beta=self._beta, llr_scale=self._llr_scale,
+                                llr_dtype=np.float32, device_id=self._device_id,
+                                crc=self.code_block_check() if self._crc_stop else None)
+        else:
+            self._codec.set_layers(n_layers)
         self._codec_layers = n_layers
 
     def _setup(self):  # NRLDPCDecoder.m:107-130
@@ -164,7 +171,9 @@ class NRLDPCDecoder(NRLDPC):
         filler = np.isnan(cw[0, 0, :K_])
         cw[np.isnan(cw)] = np.inf  # :264
         n_layers = 0
-        if self._prune:
+        if self._prune == "auto":
+            n_layers = -1
+        elif self._prune:
             act = self.active_layers()
             self._layers_seen = max(self._layers_seen, act) if self.I_HARQ else act
             n_layers = self._layers_seen
@@ -172,6 +181,7 @@ class NRLDPCDecoder(NRLDPC):
         if self._codec is None or self._codec_layers != want:
             self._make_codec(want)
         hard, iters = self._codec.decode(cw.astype(np.float32).reshape(nb * C_, -1), want_iters=True)  # :265
+        self.last_layers = self._codec.last_layers()
         self.last_iterations = iters.reshape(nb, C_)
         c_hat = hard.reshape(nb, C_, K_).astype(np.float64)
         c_hat[:, :, filler] = np.nan  # :266

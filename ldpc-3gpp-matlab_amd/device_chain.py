@@ -43,12 +43,14 @@ class DeviceDecodeChain:
             self._codec = None
 
     def _codec_for(self, n_layers):
-        if self._codec is None or self._codec_layers != n_layers:
-            self.close()
+        """One codec for the chain's lifetime; the layer count is a property of the call (nrldpc_set_layers, ABI revision 5)."""
+        if self._codec is None:
             self._codec = Codec(self.p.BG, self.p.Z_c, max_iter=self.iterations, n_layers=n_layers, early_term=True,
                                 alpha=self.alpha or 0.0, beta=self.beta, llr_scale=self.llr_scale, llr_dtype=self.llr_dtype, device_id=self.device_id,
                                 crc=self.p.code_block_check() if self.crc_stop else None)
-            self._codec_layers = n_layers
+        elif self._codec_layers != n_layers:
+            self._codec.set_layers(n_layers)
+        self._codec_layers = n_layers
         return self._codec
 
     def step(self, g_tilde):

@@ -10,17 +10,21 @@
 //
 // Commands
 //   id           = nrldpc_mex('create', BG, Z_c, iterations [, n_layers [, alpha [, beta]]])
-//                  n_layers 0 / omitted = every row of H, as the reference decodes; alpha 0 / omitted = the library's
-//                  rate-dependent check-node rule (nrldpc_default_rule)
-//   [c_hat, it]  = nrldpc_mex('decode', id, cw_tilde)   cw_tilde: (N+2*Z_c) x C double, +inf fillers, 0 punctured
-//                                                       c_hat: K x C double in {0,1}; it: C x 1 int32 iterations run
+//                  n_layers omitted / -1 = NRLDPC_LAYERS_AUTO: every call decodes the rows its own cw_tilde needs -- read off the
+//                  data, exact for any rv_id / HARQ state (include/nrldpc.h "Active layers"; at plot_BLER_vs_SNR.m's defaults 21 of
+//                  BG2's 42 rows, at R = 8/9 5 of BG1's 46); 0 = every row of H, as the reference decodes (NRLDPCDecoder.m:120);
+//                  alpha 0 / omitted = the library's rate-dependent check-node rule (nrldpc_default_rule)
+//   [c_hat, it, nl] = nrldpc_mex('decode', id, cw_tilde)   cw_tilde: (N+2*Z_c) x C double OR single, +inf fillers, 0 punctured
+//                                                       c_hat: K x C double in {0,1}; it: C x 1 int32 iterations run;
+//                                                       nl: the layer count the call ran with
+//   nrldpc_mex('set_layers', id, n_layers)              the count of the calls that follow (0 all, 4..rows, -1 auto)
 //   cw           = nrldpc_mex('encode', id, c)          c: K x C double in {0,1} (no NaN) -> (N+2*Z_c) x C double
 //   [a, b]       = nrldpc_mex('default_rule', BG, n_layers)
 //   nrldpc_mex('destroy', id)
 //   One MATLAB process, several GPUs (nrldpc_pool_*: codeword batches shard with no collective; plot_BLER_vs_SNR.m:23-27
 //   runs "parallel instances" by hand instead):
-//   pid          = nrldpc_mex('pool_create', BG, Z_c, iterations, device_ids [, chunks_per_device [, n_layers]])
-//   [c_hat, it]  = nrldpc_mex('pool_decode', pid, cw_tilde)   any number of columns, dealt to the GPUs of the pool
+//   pid          = nrldpc_mex('pool_create', BG, Z_c, iterations, device_ids [, chunks_per_device [, n_layers]])   (n_layers as above)
+//   [c_hat, it]  = nrldpc_mex('pool_decode', pid, cw_tilde)   any number of columns (double), dealt to the GPUs of the pool
 //   nrldpc_mex('pool_destroy', pid)
 // Errors carry the reference's two identifiers (NRLDPCDecoder.m:149, NRLDPC.m:240-294): callers that catch
 // 'ldpc_3gpp_matlab:UnsupportedParameters' and skip (plot_BLER_vs_SNR.m:173, testbench.m:51) keep working.
@@ -84,7 +88,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         cfg.bg = (int32_t)mxGetScalar(prhs[1]);
         cfg.Z = (int32_t)mxGetScalar(prhs[2]);
         cfg.max_iter = (int32_t)mxGetScalar(prhs[3]);                  // 'MaximumIterationCount', NRLDPCDecoder.m:41,120
-        cfg.n_layers = nrhs > 4 ? (int32_t)mxGetScalar(prhs[4]) : 0;   // 0: the full H, as the reference
+        cfg.n_layers = nrhs > 4 ? (int32_t)mxGetScalar(prhs[4]) : NRLDPC_LAYERS_AUTO; // read off each call's cw_tilde; 0: the full H
         cfg.alpha = nrhs > 5 ? (float)mxGetScalar(prhs[5]) : 0.0f;     // 0: rule chosen by the library
         cfg.beta = nrhs > 6 ? (float)mxGetScalar(prhs[6]) : 0.0f;
         cfg.early_term = 1;                                            // 'Parity check satisfied', NRLDPCDecoder.m:120
@@ -95,23 +99,34 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         g_handles[g_next] = h;
         plhs[0] = mxCreateDoubleScalar((double)g_next++);
     } else if (!strcmp(cmd, "decode")) {
-        need(nrhs == 3 && mxIsDouble(prhs[2]) && !mxIsComplex(prhs[2]), "decode needs a handle and a real double matrix.");
+        need(nrhs == 3 && (mxIsDouble(prhs[2]) || mxIsSingle(prhs[2])) && !mxIsComplex(prhs[2]),
+             "decode needs a handle and a real double or single matrix.");
         nrldpc_handle h = handle_of(prhs[1]);
         nrldpc_dims d;
         d.struct_size = sizeof d;
         check(nrldpc_get_dims(h, &d));
         need((int)mxGetM(prhs[2]) == d.N_cw, "cw_tilde should have N+2*Z_c rows.");
         const int C = (int)mxGetN(prhs[2]);
+        // the caller's array as it is: a `single` cw_tilde is half the bytes for the copy threads to read
+        check(nrldpc_set_llr_dtype(h, mxIsSingle(prhs[2]) ? NRLDPC_LLR_F32 : NRLDPC_LLR_F64));
         // bit-packed over PCIe (nrldpc_decode_packed, ABI revision 4): K/8 bytes per column come back instead of K
         const size_t KB8 = ((size_t)d.K + 7) / 8;
         std::vector<uint8_t> packed(KB8 * (size_t)(C > 0 ? C : 1));
         mxArray* it = mxCreateNumericMatrix(C, 1, mxINT32_CLASS, mxREAL);
-        check(nrldpc_decode_packed(h, mxGetPr(prhs[2]), C, packed.data(), (int32_t*)mxGetData(it)));
+        check(nrldpc_decode_packed(h, mxGetData(prhs[2]), C, packed.data(), (int32_t*)mxGetData(it)));
         plhs[0] = mxCreateDoubleMatrix(d.K, C, mxREAL);                // K x C double {0,1}, what double(step(...)) gives, :265
         double* o = mxGetPr(plhs[0]);
         for (int c = 0; c < C; ++c)
             for (int k = 0; k < d.K; ++k) o[(size_t)c * d.K + k] = (double)((packed[(size_t)c * KB8 + (k >> 3)] >> (k & 7)) & 1);
         if (nlhs > 1) plhs[1] = it; else mxDestroyArray(it);
+        if (nlhs > 2) {
+            int32_t nl = 0;
+            check(nrldpc_last_layers(h, &nl));
+            plhs[2] = mxCreateDoubleScalar((double)nl);
+        }
+    } else if (!strcmp(cmd, "set_layers")) {
+        need(nrhs == 3, "set_layers needs a handle and a layer count.");
+        check(nrldpc_set_layers(handle_of(prhs[1]), (int32_t)mxGetScalar(prhs[2])));
     } else if (!strcmp(cmd, "encode")) {
         need(nrhs == 3 && mxIsDouble(prhs[2]) && !mxIsComplex(prhs[2]), "encode needs a handle and a real double matrix.");
         nrldpc_handle h = handle_of(prhs[1]);
@@ -153,7 +168,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         cfg.bg = (int32_t)mxGetScalar(prhs[1]);
         cfg.Z = (int32_t)mxGetScalar(prhs[2]);
         cfg.max_iter = (int32_t)mxGetScalar(prhs[3]);
-        cfg.n_layers = nrhs > 6 ? (int32_t)mxGetScalar(prhs[6]) : 0;
+        cfg.n_layers = nrhs > 6 ? (int32_t)mxGetScalar(prhs[6]) : NRLDPC_LAYERS_AUTO;
         cfg.early_term = 1;                                            // 'Parity check satisfied', NRLDPCDecoder.m:120
         cfg.llr_dtype = NRLDPC_LLR_F64;
         const size_t nd = mxGetNumberOfElements(prhs[4]);
@@ -180,12 +195,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const nrldpc_dims& d = pit->second.d;
         need((int)mxGetM(prhs[2]) == d.N_cw, "cw_tilde should have N+2*Z_c rows.");
         const int C = (int)mxGetN(prhs[2]);
-        std::vector<uint8_t> hard((size_t)d.K * (size_t)(C > 0 ? C : 1));
+        const size_t KB8 = ((size_t)d.K + 7) / 8;                      // bit-packed over PCIe, as 'decode'
+        std::vector<uint8_t> packed(KB8 * (size_t)(C > 0 ? C : 1));
         mxArray* it = mxCreateNumericMatrix(C, 1, mxINT32_CLASS, mxREAL);
-        check(nrldpc_pool_decode(pit->second.p, mxGetPr(prhs[2]), C, hard.data(), (int32_t*)mxGetData(it)));
+        check(nrldpc_pool_decode_packed(pit->second.p, mxGetPr(prhs[2]), C, packed.data(), (int32_t*)mxGetData(it)));
         plhs[0] = mxCreateDoubleMatrix(d.K, C, mxREAL);
         double* o = mxGetPr(plhs[0]);
-        for (size_t i = 0; i < (size_t)d.K * C; ++i) o[i] = (double)hard[i];
+        for (int c = 0; c < C; ++c)
+            for (int k = 0; k < d.K; ++k) o[(size_t)c * d.K + k] = (double)((packed[(size_t)c * KB8 + (k >> 3)] >> (k & 7)) & 1);
         if (nlhs > 1) plhs[1] = it; else mxDestroyArray(it);
     } else if (!strcmp(cmd, "pool_destroy")) {
         need(nrhs == 2, "pool_destroy needs a pool id.");

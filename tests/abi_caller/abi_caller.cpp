@@ -1,5 +1,7 @@
 // abi_caller.cpp -- a plain C++ caller of include/nrldpc.h, the way a MEX gateway (matlab/nrldpc_mex.cpp) reaches the
 // library: host pointers only, MATLAB-style column-major doubles, one call per batch of code blocks, error codes.
+// Since round 5 it makes the gateway's REAL calls: nrldpc_decode_packed on doubles and singles, NRLDPC_LAYERS_AUTO against explicit
+// counts, nrldpc_pool_* with two logical shards, and the struct-size guard against a revision-3 caller.
 // No HIP headers, no Python.  Built by tests/test_abi_caller_gpu.py:
 //     g++ -O2 -std=c++17 -I include tests/abi_caller/abi_caller.cpp -L ldpc-3gpp-matlab_amd -lnrldpc_hip -o abi_caller
 // usage: abi_caller <bg> <Z> <C> <EsN0_dB> <iterations> [n_filler]
@@ -87,6 +89,76 @@ int main(int argc, char** argv) {
     CHECK(std::memcmp(one.data(), hard.data(), K) == 0, "single-column decode equals column 0 of the batch");
     CHECK(nrldpc_decode(h, llr.data(), -1, hard.data(), nullptr, nullptr) == NRLDPC_ERR_ARG, "negative batch is NRLDPC_ERR_ARG");
     CHECK(nrldpc_decode(h, nullptr, 1, hard.data(), nullptr, nullptr) == NRLDPC_ERR_ARG, "null llr is NRLDPC_ERR_ARG");
+
+    // what matlab/nrldpc_mex.cpp 'decode' really calls since ABI revision 4: bit-packed output, doubles in -- same bits, same counts
+    const size_t KB8 = (K + 7) / 8;
+    std::vector<uint8_t> packed(KB8 * C, 0xff);
+    std::vector<int32_t> it2(C, -1);
+    CHECK(nrldpc_decode_packed(h, llr.data(), C, packed.data(), it2.data()) == NRLDPC_OK, "nrldpc_decode_packed");
+    for (int c = 0; c < C; ++c) {
+        CHECK(it2[c] == it[c], "packed call: same iteration counts");
+        for (size_t k = 0; k < K; ++k)
+            CHECK(((packed[(size_t)c * KB8 + (k >> 3)] >> (k & 7)) & 1) == hard[(size_t)c * K + k], "packed call: same bits");
+        if (K % 8) CHECK((packed[(size_t)c * KB8 + KB8 - 1] >> (K % 8)) == 0, "unused bits of the last byte are zero");
+    }
+    // ... from a `single` array through the same handle (nrldpc_set_llr_dtype): the gateway hands over what the caller holds
+    std::vector<float> llr32(llr.begin(), llr.end());
+    std::vector<uint8_t> packed32(KB8 * C, 0xff);
+    CHECK(nrldpc_set_llr_dtype(h, NRLDPC_LLR_F32) == NRLDPC_OK, "nrldpc_set_llr_dtype");
+    CHECK(nrldpc_decode_packed(h, llr32.data(), C, packed32.data(), nullptr) == NRLDPC_OK, "nrldpc_decode_packed on singles");
+    CHECK(nrldpc_set_llr_dtype(h, NRLDPC_LLR_F64) == NRLDPC_OK && nrldpc_set_llr_dtype(h, 7) == NRLDPC_ERR_UNSUPPORTED, "llr_dtype back / invalid");
+    // (doubles are narrowed to float before anything else happens to them, so the two calls see the same values)
+    CHECK(std::memcmp(packed32.data(), packed.data(), packed.size()) == 0, "singles decode like the doubles they came from");
+
+    // ABI revision 5: the layer count belongs to the call.  The gateway creates its handles under NRLDPC_LAYERS_AUTO; a rate-matched
+    // block (here: everything above `act` rows not transmitted = LLR 0, NRLDPCDecoder.m:216-234) then decodes `act` rows -- the
+    // bits and counts of an explicit nrldpc_set_layers(act), which is what a handle CREATED with n_layers = act gives
+    const int rows = d.nrows, act = rows > 12 ? 12 : rows;
+    std::vector<double> rm(llr);
+    for (int c = 0; c < C; ++c)
+        for (size_t v = (size_t)(d.kb + act) * Z; v < N; ++v) rm[(size_t)c * N + v] = 0.0;
+    CHECK(nrldpc_count_layers(bg, Z, rm.data(), C, NRLDPC_LLR_F64) == act, "nrldpc_count_layers");
+    CHECK(nrldpc_count_layers(bg, Z, llr.data(), C, NRLDPC_LLR_F64) == rows, "nrldpc_count_layers on the full-rate block");
+    CHECK(nrldpc_set_layers(h, NRLDPC_LAYERS_AUTO) == NRLDPC_OK, "nrldpc_set_layers(AUTO)");
+    std::vector<uint8_t> h_auto(K * C, 2), h_exp(K * C, 3), h_new(K * C, 4);
+    std::vector<int32_t> it_auto(C, -1), it_exp(C, -2), it_new(C, -3);
+    int32_t nl = 0;
+    CHECK(nrldpc_decode(h, rm.data(), C, h_auto.data(), it_auto.data(), nullptr) == NRLDPC_OK, "decode under AUTO");
+    CHECK(nrldpc_last_layers(h, &nl) == NRLDPC_OK && nl == act, "AUTO found the active rows");
+    CHECK(nrldpc_decode(h, llr.data(), C, hard.data(), nullptr, nullptr) == NRLDPC_OK && nrldpc_last_layers(h, &nl) == NRLDPC_OK && nl == rows,
+          "the next call finds its own count");
+    CHECK(nrldpc_set_layers(h, act) == NRLDPC_OK, "nrldpc_set_layers(act)");
+    CHECK(nrldpc_decode(h, rm.data(), C, h_exp.data(), it_exp.data(), nullptr) == NRLDPC_OK, "decode with an explicit count");
+    nrldpc_cfg cfg2 = cfg;
+    cfg2.n_layers = act;
+    nrldpc_handle h2 = nullptr;
+    CHECK(nrldpc_create(&cfg2, &h2) == NRLDPC_OK, "create with n_layers");
+    CHECK(nrldpc_decode(h2, rm.data(), C, h_new.data(), it_new.data(), nullptr) == NRLDPC_OK, "decode on that handle");
+    nrldpc_destroy(h2);
+    CHECK(h_auto == h_exp && h_auto == h_new && it_auto == it_exp && it_auto == it_new, "AUTO == set_layers == create(n_layers), bits and counts");
+    CHECK(nrldpc_set_layers(h, 3) == NRLDPC_ERR_UNSUPPORTED && nrldpc_set_layers(h, rows + 1) == NRLDPC_ERR_UNSUPPORTED, "invalid counts are refused");
+
+    // a caller built against ABI revision 3 (nrldpc_cfg without the crc_* tail) is refused, not misread
+    nrldpc_cfg old = cfg;
+    old.struct_size = (uint32_t)(sizeof cfg - 3 * sizeof(int32_t));
+    CHECK(nrldpc_create(&old, &h2) == NRLDPC_ERR_ARG && h2 == nullptr, "a revision-3-sized nrldpc_cfg is refused");
+    nrldpc_pool_handle pool = nullptr;
+    const int32_t ids[2] = {0, 0};
+    CHECK(nrldpc_pool_create(&old, ids, 2, 2, &pool) == NRLDPC_ERR_ARG && pool == nullptr, "... by nrldpc_pool_create too");
+
+    // the multi-GPU form the gateway's 'pool_*' commands use, two logical shards on device 0: same bits as the handle
+    cfg2 = cfg;
+    cfg2.n_layers = NRLDPC_LAYERS_AUTO;
+    CHECK(nrldpc_pool_create(&cfg2, ids, 2, 2, &pool) == NRLDPC_OK && nrldpc_pool_size(pool) == 2, "nrldpc_pool_create");
+    std::vector<uint8_t> p_hard(K * C, 5), p_packed(KB8 * C, 0xff);
+    std::vector<int32_t> p_it(C, -4), split(2, -1);
+    CHECK(nrldpc_pool_decode(pool, rm.data(), C, p_hard.data(), p_it.data()) == NRLDPC_OK, "nrldpc_pool_decode");
+    CHECK(p_hard == h_auto && p_it == it_auto, "pool == handle (AUTO found once for the whole batch)");
+    CHECK(nrldpc_pool_last_split(pool, split.data()) == NRLDPC_OK && split[0] + split[1] == C, "every codeword decoded once");
+    CHECK(nrldpc_pool_decode_packed(pool, llr.data(), C, p_packed.data(), p_it.data()) == NRLDPC_OK, "nrldpc_pool_decode_packed");
+    CHECK(std::memcmp(p_packed.data(), packed.data(), packed.size()) == 0 && p_it == it2, "pool, bit-packed == handle, bit-packed");
+    CHECK(nrldpc_pool_set_layers(pool, 0) == NRLDPC_OK && nrldpc_pool_set_layers(pool, 2) == NRLDPC_ERR_UNSUPPORTED, "nrldpc_pool_set_layers");
+    nrldpc_pool_destroy(pool);
     nrldpc_destroy(h);
     std::printf("{\"bg\": %d, \"Z\": %d, \"C\": %d, \"EsN0_dB\": %.2f, \"block_errors\": %d, \"max_iterations\": %d, "
                 "\"alpha\": %.4f, \"beta\": %.4f, \"version\": \"%s\", \"build\": \"%s\"}\n",

@@ -50,6 +50,9 @@ class OracleCodec:
                               n_layers=self.n_layers, early_term=True, alpha=self.alpha, beta=self.beta * 8)
         return (h, it) if want_iters else h
 
+    def last_layers(self):
+        return self.n_layers
+
     def close(self):
         pass
 

@@ -14,6 +14,7 @@ typedef enum { mxUNKNOWN_CLASS = 0, mxDOUBLE_CLASS = 6, mxUINT8_CLASS = 9, mxINT
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 bool mxIsChar(const mxArray*);
 bool mxIsDouble(const mxArray*);
+bool mxIsSingle(const mxArray*);
 bool mxIsComplex(const mxArray*);
 int mxGetString(const mxArray*, char*, mwSize);
 double mxGetScalar(const mxArray*);

@@ -44,15 +44,22 @@ def _threads():
         pass
     return n
 
-# name, bg, Z, K' (payload + CRC bits), E (transmitted bits, rv0), active layers, iteration cap, Es/N0 grid, blocks
-CASES = [
-    ("cfg1 BG2 A=100 R=1/3 QPSK 10it", 2, 20, 116, 300, 12, 10, [0.0, 0.5, 1.0, 1.5, 2.0], 4096),
-    ("cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25, [-1.6, -1.5, -1.4, -1.3, -1.2], 1024),
-    ("cfg3 BG2 Z=384 R=1/5 25it", 2, 384, 3840, 19120, 42, 25, [-4.2, -4.1, -4.0, -3.9, -3.8], 512),
-    ("cfg3 BG2 Z=384 R=1/3 25it", 2, 384, 3840, 11472, 22, 25, [-1.5, -1.4, -1.3, -1.2, -1.1], 512),
-    ("cfg3 BG2 Z=384 R=2/3 25it", 2, 384, 3840, 5736, 7, 25, [2.6, 2.8, 3.0, 3.2, 3.4], 512),
-    ("cfg5 BG1 Z=384 R=8/9 25it", 1, 384, 8448, 9478, 5, 25, [5.8, 6.0, 6.2, 6.4, 6.6], 512),
-]
+import bler_cases as BC  # noqa: E402  (the cases, their seeded inputs and the committed sum-product outcomes)
+from bler_cases import CASES, CASES_1E2, CASES_50  # noqa: E402
+
+REF = BC.Ref(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bler_ref.npz")
+             if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bler_ref.npz")) else None)
+
+
+def sum_product(orc, key, inp, llr, bg, Z, nl, cap):
+    """Block errors and mean sweeps of the reference-semantics decoder on these LLRs: the committed outcome of
+    tests/golden/make_bler_ref.py when it was computed from exactly these LLRs (tests/test_bler_ref.py re-computes slices of it
+    on the CPU suite), else orc_decode_bp_flood here and now."""
+    got = REF.get(key, llr, inp.Kp, inp.info, llr.shape[0])
+    if got is not None:
+        return got
+    hb, ib = orc.decode_bp_flood(bg, Z, llr, cap, n_layers=nl, nthreads=_threads())
+    return (hb[:, :inp.Kp] != inp.info[:, :inp.Kp]).any(1), float(ib.mean())
 
 
 def crossing(snrs, blers, nblk, target=TARGET):
@@ -68,27 +75,19 @@ def crossing(snrs, blers, nblk, target=TARGET):
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_db_gap_to_flooding_sum_product(pkg, orc, case):
     name, bg, Z, Kp, E, nl, iters, snrs, nblk = case
-    rows, cols, kb = BG_DIMS[bg]
-    K = kb * Z
-    rng = np.random.default_rng(zlib.crc32(name.encode()))
     codec = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=True, llr_dtype=np.float32)  # alpha = 0: library rule
     assert (codec.alpha, codec.beta) == pkg.default_rule(bg, nl)
-    info = rng.integers(0, 2, (nblk, K), dtype=np.uint8)
-    info[:, Kp:] = 0
-    cw = codec.encode(info)
-    noise = rng.standard_normal(cw.shape)
+    inp = BC.inputs_gap(case, orc.encode)
+    info = inp.info
+    assert (codec.encode(info[:16]) == inp.cw[:16]).all()
     b_gpu, b_bp, it_gpu, it_bp = [], [], [], []
     for snr in snrs:
-        mu = 2 * 10 ** (snr / 10)                   # QPSK, N0 = 10^(-EsN0/10)  (plot_BLER_vs_SNR.m:105-106)
-        llr = (1 - 2.0 * cw) * mu + np.sqrt(2 * mu) * noise
-        llr[:, : 2 * Z] = 0                         # punctured systematic columns (NRLDPCDecoder.m:262)
-        llr[:, 2 * Z + E + (K - Kp):] = 0           # beyond the E transmitted non-filler bits (k0 = 0)
-        llr[:, Kp:K] = np.inf                       # fillers (NRLDPCDecoder.m:264)
+        llr = inp.llr_at(snr)
         hg, ig = codec.decode(llr.astype(np.float32), want_iters=True)
-        hb, ib = orc.decode_bp_flood(bg, Z, llr, iters, n_layers=nl, nthreads=_threads())
+        eb, sb = sum_product(orc, "gap/%s/%g" % (name, snr), inp, llr, bg, Z, nl, iters)
         b_gpu.append(float((hg[:, :Kp] != info[:, :Kp]).any(1).mean()))
-        b_bp.append(float((hb[:, :Kp] != info[:, :Kp]).any(1).mean()))
-        it_gpu.append(float(ig.mean())); it_bp.append(float(ib.mean()))
+        b_bp.append(float(eb.mean()))
+        it_gpu.append(float(ig.mean())); it_bp.append(sb)
         if snr == snrs[len(snrs) // 2]:             # and the GPU result is the oracle's, bit for bit, in the waterfall
             ho, io = orc.decode_nmsq(bg, Z, llr[:8].astype(np.float32).astype(np.float64), iters, n_layers=nl,
                                      early_term=True, **rule_kw(codec))
@@ -114,45 +113,20 @@ def test_db_gap_to_flooding_sum_product(pkg, orc, case):
     assert all(b_gpu[i] >= b_gpu[i + 1] - 0.02 for i in range(len(snrs) - 1))  # monotone up to sampling noise
 
 
-# name (as in CASES), bg, Z, K', E, layers, iteration cap, grid at equal caps, grid of the 50-sweep sum-product reference, blocks
-CASES_1E2 = [
-    # (three grid points each, bracketing the crossings found with five -- profiles/r03_bler_gap.json of the first run: the
-    # sum-product oracle on 4096 blocks is what the GPU suite's wall time is made of)
-    ("cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25, [-1.35, -1.30, -1.25], [-1.65, -1.60, -1.55], 4096),
-    ("cfg3 BG2 Z=384 R=1/3 25it", 2, 384, 3840, 11472, 22, 25, [-1.30, -1.20, -1.10], [-1.60, -1.50, -1.40], 4096),
-]
-
-
 @pytest.mark.parametrize("case", CASES_1E2, ids=[c[0] for c in CASES_1E2])
 def test_db_gap_at_bler_1e2(pkg, orc, case):
     name, bg, Z, Kp, E, nl, iters, snrs, snrs50, nblk = case
-    rows, cols, kb = BG_DIMS[bg]
-    K = kb * Z
-    rng = np.random.default_rng(zlib.crc32((name + " 1e-2").encode()))
     codec = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=True, llr_dtype=np.float32)
-    info = rng.integers(0, 2, (nblk, K), dtype=np.uint8)
-    info[:, Kp:] = 0
-    cw = codec.encode(info)
-    noise = rng.standard_normal(cw.shape).astype(np.float32)
-    nth = _threads()
-
-    def llr_at(snr):
-        mu = 2 * 10 ** (snr / 10)
-        llr = ((1 - 2.0 * cw) * mu + np.sqrt(2 * mu) * noise).astype(np.float64)
-        llr[:, : 2 * Z] = 0
-        llr[:, 2 * Z + E + (K - Kp):] = 0
-        llr[:, Kp:K] = np.inf
-        return llr
+    inp = BC.inputs_1e2(case, orc.encode)
+    info = inp.info
     b_gpu, b_bp, b_bp50 = [], [], []
     for snr in snrs:
-        llr = llr_at(snr)
+        llr = inp.llr_at(snr)
         hg = codec.decode(llr.astype(np.float32))
-        hb, _ = orc.decode_bp_flood(bg, Z, llr, iters, n_layers=nl, nthreads=nth)
         b_gpu.append(float((hg[:, :Kp] != info[:, :Kp]).any(1).mean()))
-        b_bp.append(float((hb[:, :Kp] != info[:, :Kp]).any(1).mean()))
+        b_bp.append(float(sum_product(orc, "1e2/%s/%g" % (name, snr), inp, llr, bg, Z, nl, iters)[0].mean()))
     for snr in snrs50:  # the reference's default iteration count (NRLDPCDecoder.m:41)
-        hb, _ = orc.decode_bp_flood(bg, Z, llr_at(snr), 50, n_layers=nl, nthreads=nth)
-        b_bp50.append(float((hb[:, :Kp] != info[:, :Kp]).any(1).mean()))
+        b_bp50.append(float(sum_product(orc, "1e2_50/%s/%g" % (name, snr), inp, inp.llr_at(snr), bg, Z, nl, 50)[0].mean()))
     codec.close()
     x_gpu, x_bp, x_bp50 = crossing(snrs, b_gpu, nblk, 1e-2), crossing(snrs, b_bp, nblk, 1e-2), crossing(snrs50, b_bp50, nblk, 1e-2)
     extra = {"blocks_at_bler_0.01": nblk, "EsN0_dB_at_bler_0.01_grid": snrs, "bler_gpu_fine": b_gpu, "bler_sum_product_fine": b_bp,
@@ -194,41 +168,21 @@ def _record(name, extra):
 # layered min-sum has converged by then (25 -> 50 iterations moves its BLER 1e-2 point by 0.08 dB at the headline code), flooding
 # sum-product has not (25 -> 50 sweeps: 0.25 dB), so at 50 the gap is the min-sum approximation itself.
 BOUND_DB_50 = 0.25
-# name, bg, Z, K', E, layers, grid of the GPU decoder, grid of the sum-product oracle, blocks
-CASES_50 = [
-    ("cfg2 headline BG1 Z=384 R=1/3 50it", 1, 384, 8448, 25272, 46, [-1.50, -1.45, -1.40, -1.35, -1.30], [-1.70, -1.65, -1.60, -1.55], 4096),
-    ("cfg3 BG2 Z=384 R=1/3 50it", 2, 384, 3840, 11472, 22, [-1.55, -1.45, -1.35, -1.25, -1.15], [-1.75, -1.65, -1.55, -1.45, -1.35], 4096),
-]
-
-
 @pytest.mark.parametrize("case", CASES_50, ids=[c[0] for c in CASES_50])
 def test_db_gap_at_the_reference_default_of_50_iterations(pkg, orc, case):
     """Equal caps at the reference's DEFAULT `iterations = 50` (NRLDPCDecoder.m:41): 50 layered offset-min-sum iterations on
     the GPU against 50 flooding sum-product sweeps, identical noise, crossing of BLER 1e-2 on 4096 blocks."""
     name, bg, Z, Kp, E, nl, snrs, snrs_bp, nblk = case
-    rows, cols, kb = BG_DIMS[bg]
-    K = kb * Z
-    rng = np.random.default_rng(zlib.crc32(name.encode()))
     codec = pkg.Codec(bg, Z, max_iter=50, n_layers=nl, early_term=True, llr_dtype=np.float32)
-    info = rng.integers(0, 2, (nblk, K), dtype=np.uint8)
-    info[:, Kp:] = 0
-    cw = codec.encode(info)
-    noise = rng.standard_normal(cw.shape).astype(np.float32)
-
-    def llr_at(snr):
-        mu = 2 * 10 ** (snr / 10)
-        llr = ((1 - 2.0 * cw) * mu + np.sqrt(2 * mu) * noise).astype(np.float64)
-        llr[:, : 2 * Z] = 0
-        llr[:, 2 * Z + E + (K - Kp):] = 0
-        llr[:, Kp:K] = np.inf
-        return llr
+    inp = BC.inputs_50(case, orc.encode)
+    info = inp.info
     b_gpu, it_gpu, b_bp, it_bp = [], [], [], []
     for snr in snrs:
-        hg, ig = codec.decode(llr_at(snr).astype(np.float32), want_iters=True)
+        hg, ig = codec.decode(inp.llr_at(snr).astype(np.float32), want_iters=True)
         b_gpu.append(float((hg[:, :Kp] != info[:, :Kp]).any(1).mean())); it_gpu.append(float(ig.mean()))
     for snr in snrs_bp:
-        hb, ib = orc.decode_bp_flood(bg, Z, llr_at(snr), 50, n_layers=nl, nthreads=_threads())
-        b_bp.append(float((hb[:, :Kp] != info[:, :Kp]).any(1).mean())); it_bp.append(float(ib.mean()))
+        eb, sb = sum_product(orc, "50/%s/%g" % (name, snr), inp, inp.llr_at(snr), bg, Z, nl, 50)
+        b_bp.append(float(eb.mean())); it_bp.append(sb)
     codec.close()
     x_gpu, x_bp = crossing(snrs, b_gpu, nblk, 1e-2), crossing(snrs_bp, b_bp, nblk, 1e-2)
     rec = {"blocks": nblk, "iterations": 50, "EsN0_dB_gpu": snrs, "bler_gpu": b_gpu, "mean_iters_gpu": it_gpu,

@@ -131,24 +131,55 @@ def test_mex_gateway_compiles_against_the_stub_mex_api():
                            "-I" + os.path.join(ROOT, "tests", "mex_stub"), "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "matlab", "nrldpc_mex.cpp")])
     src = open(os.path.join(ROOT, "matlab", "nrldpc_mex.cpp")).read()
-    for cmd in ("create", "decode", "encode", "destroy", "default_rule", "pool_create", "pool_decode", "pool_destroy"):
+    for cmd in ("create", "decode", "set_layers", "encode", "destroy", "default_rule", "pool_create", "pool_decode", "pool_destroy"):
         assert '"%s"' % cmd in src, cmd
 
 
 def test_abi_revision_and_struct_size_guard(pkg):
-    """ABI revision 3 (kept by revision 4, which only adds nrldpc_decode_packed): nrldpc_cfg / nrldpc_dims carry their size; a caller built against another revision is refused
-    instead of having memory past its struct read or written."""
+    """ABI revision 3 (kept by revisions 4 and 5, which add entry points and a value of n_layers, not fields): nrldpc_cfg /
+    nrldpc_dims carry their size; a caller built against another revision is refused instead of having memory past its struct
+    read or written."""
     C = pkg._capi
     lib = pkg.load()
-    assert lib.nrldpc_abi_version() == C.ABI_VERSION == 4
+    assert lib.nrldpc_abi_version() == C.ABI_VERSION == 5
     hdr = open(os.path.join(ROOT, "include", "nrldpc.h")).read()
-    assert "#define NRLDPC_ABI_VERSION 4" in hdr
+    assert "#define NRLDPC_ABI_VERSION 5" in hdr and "#define NRLDPC_LAYERS_AUTO (-1)" in hdr
     cfg = C.Cfg(1, 384, 0, 10, 1, 0.0, 0, 0, 0, 0)
     assert cfg.struct_size == ctypes.sizeof(C.Cfg)
     cfg.struct_size = ctypes.sizeof(C.Cfg) - 4  # the r1 layout (no beta)
     h = ctypes.c_void_p()
     assert lib.nrldpc_create(ctypes.byref(cfg), ctypes.byref(h)) == C.ERR_ARG and h.value is None
     assert b"struct_size" in lib.nrldpc_last_error()
+
+
+def test_count_layers_is_the_definition_of_auto(pkg):
+    """nrldpc_count_layers (host function, no device): NRLDPC_LAYERS_AUTO's rule -- n = max(4, c - kb + 1) for the highest
+    base-graph column c holding anything but +-0 / NaN in any codeword of the call -- against numpy, for the three boundary
+    dtypes, odd lifting sizes (unaligned blocks) and the values that must not count (NaN, -0) or must (+-inf, denormals)."""
+    import numpy as np
+    C = pkg._capi
+    rng = np.random.default_rng(21)
+    for bg, (rows, cols, kb) in ((1, (46, 68, 22)), (2, (42, 52, 10))):
+        for Z in (2, 7, 15, 64, 208, 384):
+            for dt in (np.float64, np.float32, np.float16):
+                for trial in range(6):
+                    B = int(rng.integers(1, 9))
+                    x = np.zeros((B, cols, Z), dt)
+                    top = int(rng.integers(0, cols))
+                    x[:, : top + 1] = rng.standard_normal((B, top + 1, Z)).astype(dt)
+                    if trial == 1:    # only ONE value in the top block of ONE codeword, the last element
+                        x[:, top] = 0; x[B - 1, top, Z - 1] = np.finfo(dt).tiny
+                    if trial == 2 and top + 2 < cols:   # things that do not count, above the top
+                        x[0, top + 1, 0] = np.nan; x[B - 1, top + 2, Z - 1] = -0.0
+                    if trial == 3 and top + 1 < cols:   # ... and one that does
+                        top += 1; x[B // 2, top, Z // 2] = -np.inf
+                    if trial == 4:
+                        x[:] = 0; top = 0
+                    nz = ((x != 0) & ~np.isnan(x)).any(axis=(0, 2))
+                    want = max(4, (int(np.nonzero(nz)[0].max()) if nz.any() else 0) - kb + 1)
+                    assert C.count_layers(bg, Z, x.reshape(B, -1)) == want, (bg, Z, dt, trial, top)
+    assert pkg.load().nrldpc_count_layers(3, 384, None, 0, 0) == -1 and pkg.load().nrldpc_count_layers(1, 100, None, 0, 0) == -1
+    assert C.count_layers(1, 384, np.zeros((0, 68 * 384), np.float32)) == 4
 
 
 def test_committed_profile_belongs_to_the_tree_kernels(pkg):
@@ -204,4 +235,6 @@ def test_kernel_lists_of_the_build_and_of_the_dispatch_agree():
         nc, ext = (26, 42) if b == 1 else (14, 38)
         image = nc * (256 + (zc + 64) * 4) + 256 + 4 * ((n + 1 + 3) // 4 * 4)
         assert image <= 160 * 1024 and nc * (256 + (zc + 64) * 4) < 65536, (b, z, n)  # LDS budget; 16-bit LDS immediates
-        assert n + 1 <= 2 * waves * 64  # the flag words are cleared by one pass of the workgroup's threads
+        # the flag words are cleared by raw thread id in one pass, and the lanes >= blk of every wave have retired by then
+        # (the kernel's own static_assert)
+        assert n + 1 <= (2 * waves * 64 if blk == 64 else blk), (b, z, n)

@@ -280,7 +280,10 @@ CRC24A, CRC24B, CRC16 = (0x1864CFB, 24), (0x1800063, 24), (0x11021, 16)  # get_3
 @pytest.mark.parametrize("bg,Z,nl,Kp,crc,esn0", [
     (1, 384, 0, 8448, CRC24A, -0.9), (1, 384, 5, 8448, CRC24A, 6.3), (1, 384, 17, 8000, CRC24B, 2.1), (2, 384, 22, 3840, CRC16, -0.6),
     (2, 384, 0, 3000, CRC24B, -2.4), (1, 320, 0, 7040, CRC24B, -0.8), (1, 256, 30, 5632, CRC24A, 0.3), (2, 208, 21, 1957, CRC24B, -0.2),
-    (2, 20, 12, 116, CRC16, 1.8), (1, 104, 0, 2288, CRC24A, -0.6), (1, 88, 9, 1900, CRC24B, 4.2), (2, 7, 0, 70, CRC16, -1.5)])
+    (2, 20, 12, 116, CRC16, 1.8), (1, 104, 0, 2288, CRC24A, -0.6), (1, 88, 9, 1900, CRC24B, 4.2), (2, 7, 0, 70, CRC16, -1.5),
+    # the one-thread-per-row form with blocks of 48 rows and FOUR codewords per workgroup -- 80 slot words cleared by
+    # lanes of which 48..63 of every wave have retired; all rows and pruned
+    (2, 144, 0, 1440, CRC24B, -2.4), (2, 144, 17, 1300, CRC16, 0.1)])
 def test_crc_aided_stop(pkg, orc, bg, Z, nl, Kp, crc, esn0):
     """nrldpc_cfg.early_term = 2: a codeword stops when its parity checks hold OR the CRC over its first K'
     hard decisions does (and they are not all zero).  Hard decisions and iteration counts against oracle/orc_decode_onmsq_crc;

@@ -98,3 +98,24 @@ def test_bench_rank_protocol_runs_under_gloo():
     # the strong-scaled leg (BASELINE configs[4]) cuts ONE job over the ranks: contiguous halves of the 65536 codewords
     leg = rec["cfg5_strong"]
     assert leg["scaling"] == "strong" and [g["codewords"] for g in leg["per_gpu"]] == [32768, 32768]
+
+
+def test_bench_starts_its_own_ranks_and_refuses_a_wrong_rank_count():
+    """`python bench.py --gpus N` launched PLAINLY (no torch.distributed.run, WORLD_SIZE unset) must itself
+    start N ranks -- the line then says n_gpus: N and names the process group's world size -- and a launcher whose rank count
+    differs from --gpus is refused without a JSON line (a `--gpus 8` run can no longer print n_gpus: 1)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+                        "--dry-run"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["comm"] == {"backend": "gloo", "world_size": 2}
+    assert [g["codewords"] for g in rec["cfg5_strong"]["per_gpu"]] == [32768, 32768]
+    for world in ("1", "4"):
+        q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True,
+                           timeout=120, cwd=ROOT, env=dict(env, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0"))
+        assert q.returncode != 0 and "--gpus 8 but WORLD_SIZE=" + world in q.stderr and "{" not in q.stdout

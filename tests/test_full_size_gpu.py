@@ -302,6 +302,23 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert leg["scaling"] == "strong" and leg["n_gpus"] == 2 and leg["value"] > 1.0
     assert [g["codewords"] for g in leg["per_gpu"]] == [2048, 2048]
     assert all(g["bler"] < 0.05 and 1.0 <= g["mean_iterations"] < 10.0 and 0.0 < g["hbm_frac"] < 1.0 for g in leg["per_gpu"])
+    assert rec["comm"] == {"backend": "gloo", "world_size": 2, "rccl_version": None}
+    # ... and launched PLAINLY: `python bench.py --gpus 2` starts its two ranks itself
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512",
+                        "--backend", "gloo", "--share-gpu", "--cfg5-total", "2048", "--cfg5-steps", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["comm"]["world_size"] == 2 and rec["value"] > 1.0 and len(rec["roofline"]["per_gpu"]) == 2
+    # without --share-gpu a box with one GPU cannot run two ranks: refused with the device count, no line
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert p.returncode != 0 and "HIP device(s) visible" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_cfg5_full_batch_65536_through_eight_shards(pkg, orc):
