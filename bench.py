@@ -280,19 +280,28 @@ def cpu_baseline(llr_host_f64, info_host, rule):
 def e2e_host_path(nrldpc, info_host, llr_host_f16, rule, reps=7):
     """PCIe-inclusive rate through the host-pointer entry points (pageable arrays as a MEX gateway would hand them over), same
     codewords, 25 iterations, no early stop; median of `reps` calls per boundary dtype after ONE untimed call of the same size
-    (the first call of a size allocates the pinned slots and device staging).  `f16` / `f64_matlab_double`: nrldpc_decode_packed
-    (bit-packed hard decisions, what matlab/nrldpc_mex.cpp calls); `*_byte_per_bit`: nrldpc_decode.  Never `value`."""
+    (the first call of a size allocates the pinned slots and device staging).  `f16` / `f32_matlab_single` / `f64_matlab_double`:
+    nrldpc_decode_packed (bit-packed hard decisions, what matlab/nrldpc_mex.cpp calls); `*_byte_per_bit`: nrldpc_decode.  The
+    output array is allocated once per leg, as the gateway's is (a std::vector of the call) and as a caller that decodes batch
+    after batch does; `f16_byte_per_bit_fresh_output_array` is round 4's way -- a new 35 MB numpy array every call, mmap'd,
+    page-faulted by the copy threads and munmap'd each time -- which is where that round's "25-35 ms stall in every second call"
+    came from (profiles/r05_host_stall.txt).  Never `value`."""
     out = {}
-    for name, dt, packed in (("f16", np.float16, True), ("f64_matlab_double", np.float64, True),
-                             ("f16_byte_per_bit", np.float16, False), ("f64_byte_per_bit", np.float64, False)):
+    legs = (("f16", np.float16, True, True), ("f32_matlab_single", np.float32, True, True), ("f64_matlab_double", np.float64, True, True),
+            ("f16_byte_per_bit", np.float16, False, True), ("f64_byte_per_bit", np.float64, False, True),
+            ("f16_byte_per_bit_fresh_output_array", np.float16, False, False))
+    for name, dt, packed, reuse in legs:
         c = nrldpc.Codec(BG, Z, max_iter=ITERS, n_layers=0, early_term=False, llr_dtype=dt, alpha=rule[0], beta=rule[1])
         x = llr_host_f16.astype(dt)
         call = c.decode_packed if packed else c.decode
-        call(x)
+        buf = np.empty((x.shape[0], (K + 7) // 8 if packed else K), np.uint8) if reuse else None
+        if buf is not None:
+            buf[:] = 0  # touched once, like any array a caller has used before
+        call(x, out=buf)
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
-            h = call(x)
+            h = call(x, out=buf)
             ts.append(time.perf_counter() - t0)
         c.close()
         if packed:
@@ -303,7 +312,46 @@ def e2e_host_path(nrldpc, info_host, llr_host_f16, rule, reps=7):
         out[name] = {"ms_median": ts[len(ts) // 2] * 1e3, "ms_min": ts[0] * 1e3, "ms_max": ts[-1] * 1e3,
                      "value": n * K / ts[len(ts) // 2] / 1e9, "unit": "Gbit/s", "runs": reps,
                      "host_bytes_in": int(x.nbytes), "host_bytes_out": int(n * ((K + 7) // 8 if packed else K))}
+    out["r89_active_layers"] = e2e_active_layers(nrldpc, reps)
     return out
+
+
+def e2e_active_layers(nrldpc, reps=7, n=4096):
+    """What ABI revision 5 gives the reference's seam (NRLDPCDecoder.m:265: the decoder sees cw_tilde and nothing else): BG1 Z=384
+    at R = 8/9 (BASELINE configs[4]: G = 9478, 27 of 68 columns transmitted, 5 of 46 rows active), MATLAB doubles through
+    nrldpc_decode_packed with the parity stop, (a) every row of H as the reference decodes it and as the gateway did until
+    revision 4, (b) NRLDPC_LAYERS_AUTO -- the count read off the LLRs, what `nrldpc_mex('create', BG, Z_c, iterations)` now asks
+    for, (c) the count given explicitly.  Same hard decisions in all three (asserted); PCIe-inclusive times."""
+    E, esn0 = 9478, 7.5
+    c = nrldpc.Codec(BG, Z, max_iter=ITERS, n_layers=0, early_term=True, llr_dtype=np.float64)
+    rng = np.random.default_rng(89)
+    info = rng.integers(0, 2, (n, K), dtype=np.uint8)
+    cw = c.encode(info)
+    mu = 2 * 10 ** (esn0 / 10)
+    x = (1 - 2.0 * cw) * mu + np.sqrt(2 * mu) * rng.standard_normal(cw.shape)
+    x[:, : 2 * Z] = 0
+    x[:, 2 * Z + E:] = 0
+    buf = np.zeros((n, (K + 7) // 8), np.uint8)
+    res, ref = {}, None
+    for name, nl in (("all_rows_as_the_reference", 0), ("auto", -1), ("explicit_5_rows", 5)):
+        c.set_layers(nl)
+        c.decode_packed(x, out=buf)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            c.decode_packed(x, out=buf)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        h = np.unpackbits(buf, axis=1, bitorder="little")[:, :K]
+        if ref is None:
+            ref = h.copy()
+        res[name] = {"ms_median": ts[len(ts) // 2] * 1e3, "ms_min": ts[0] * 1e3, "ms_max": ts[-1] * 1e3, "layers": c.last_layers(),
+                     "value": n * K / ts[len(ts) // 2] / 1e9, "unit": "Gbit/s", "block_errors": int((h != info).any(1).sum()),
+                     "same_bits_as_all_rows": bool((h == ref).all())}
+    c.close()
+    res["speedup_auto_over_all_rows"] = res["all_rows_as_the_reference"]["ms_median"] / res["auto"]["ms_median"]
+    res["config"] = "BG1 Z=384 R=8/9 (G=9478), %d codewords of MATLAB doubles, parity stop, Es/N0 %.1f dB" % (n, esn0)
+    return res
 
 
 def dry_run(args, torch):

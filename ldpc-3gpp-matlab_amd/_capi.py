@@ -242,12 +242,17 @@ class Codec:
             pass
 
     # -- host-pointer entry points (numpy arrays) -------------------------------------------------
-    def decode(self, llr, want_iters=False, want_app=False):
+    def decode(self, llr, want_iters=False, want_app=False, out=None):
+        """out: a (B, K) uint8 array to decode into.  A caller that decodes batch after batch should pass one: a fresh 35 MB
+        array per call is mmap'd, page-faulted by sixteen copy threads and munmap'd every time -- 3-5 ms on top of a 4 ms call and
+        20-30 ms every few calls (profiles/r05_host_stall.txt; what round 4 recorded as a stall of this entry point)."""
         llr = np.ascontiguousarray(llr, self.llr_dtype)
         if llr.size % self.N_cw:
             raise NRLDPCError("llr should hold a whole number of codewords of length %d" % self.N_cw)
         B = llr.size // self.N_cw
-        hard = np.empty((B, self.K), np.uint8)
+        if out is not None and (out.shape != (B, self.K) or out.dtype != np.uint8 or not out.flags.c_contiguous):
+            raise NRLDPCError("out should be a C-contiguous uint8 array of shape (%d, %d)" % (B, self.K))
+        hard = out if out is not None else np.empty((B, self.K), np.uint8)
         iters = np.empty(B, np.int32) if want_iters else None
         app = np.empty((B, self.N_cw), np.float32) if want_app else None
         check(self._lib.nrldpc_decode(self._h, _ptr(llr), B, _ptr(hard), _ptr(iters), _ptr(app)))
@@ -258,14 +263,16 @@ class Codec:
             out += (app,)
         return out[0] if len(out) == 1 else out
 
-    def decode_packed(self, llr, want_iters=False):
+    def decode_packed(self, llr, want_iters=False, out=None):
         """nrldpc_decode_packed: hard decisions as [B][ceil(K/8)] bytes, bit k of a codeword in byte k // 8 at bit k % 8
-        (np.unpackbits(out, axis=1, bitorder="little")[:, :K] gives decode()'s array)."""
+        (np.unpackbits(out, axis=1, bitorder="little")[:, :K] gives decode()'s array).  out: see decode()."""
         llr = np.ascontiguousarray(llr, self.llr_dtype)
         if llr.size % self.N_cw:
             raise NRLDPCError("llr should hold a whole number of codewords of length %d" % self.N_cw)
         B = llr.size // self.N_cw
-        packed = np.empty((B, (self.K + 7) // 8), np.uint8)
+        if out is not None and (out.shape != (B, (self.K + 7) // 8) or out.dtype != np.uint8 or not out.flags.c_contiguous):
+            raise NRLDPCError("out should be a C-contiguous uint8 array of shape (%d, %d)" % (B, (self.K + 7) // 8))
+        packed = out if out is not None else np.empty((B, (self.K + 7) // 8), np.uint8)
         iters = np.empty(B, np.int32) if want_iters else None
         check(self._lib.nrldpc_decode_packed(self._h, _ptr(llr), B, _ptr(packed), _ptr(iters)))
         return (packed, iters) if want_iters else packed

@@ -15,8 +15,12 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 # NRLDPC_BUILD_AB=1: the A/B build -- both decoder forms (one / two threads per row) for every (BG, Z), chosen at run time by
 # NRLDPC_SPLIT=0/1 -- into its own library and object directory; load it with NRLDPC_LIB=<path> (tools/bench_all_z.py / tools/bench_configs.py with NRLDPC_SPLIT=0/1 and OUT_SUFFIX)
 AB = bool(os.environ.get("NRLDPC_BUILD_AB"))
-LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip_ab.so" if AB else "libnrldpc_hip.so")  # env override: kernel experiments
-OBJDIR = os.path.join(HERE, "build_ab" if AB else "build")
+# NRLDPC_BUILD_ALLMODES=1: the experiment build in which EVERY interleaved entry is compiled for, and serves, all three modes (fixed
+# iterations, parity stop with all rows, parity stop with pruned rows) -- what tools/ab_ilv.py measures the list's mode bits from;
+# its own library and object directory (seed the directory with a copy of build/: only the changed units recompile)
+ALLMODES = bool(os.environ.get("NRLDPC_BUILD_ALLMODES"))
+LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip_ab.so" if AB else "libnrldpc_hip_allmodes.so" if ALLMODES else "libnrldpc_hip.so")  # env override: kernel experiments
+OBJDIR = os.path.join(HERE, "build_ab" if AB else "build_allmodes" if ALLMODES else "build")
 SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_channel.hip",
            "nrldpc_expand.hip", "nrldpc_capi.hip", "nrldpc_host_quant.cpp"]  # .cpp: host-only C++ (no device pass)
 Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
@@ -147,7 +151,8 @@ def build_lib(force=False, verbose=False, jobs=None):
     os.makedirs(OBJDIR, exist_ok=True)
     inc = ["-I" + INCLUDE, "-I" + CSRC]
     units = [(os.path.join(CSRC, f), os.path.join(OBJDIR, os.path.splitext(f)[0] + ".o"),
-              ['-DNRLDPC_BUILD_ID="%s"' % sid, '-DNRLDPC_KERNEL_ID="%s"' % kernel_id()] if f == "nrldpc_capi.hip" else [])
+              ['-DNRLDPC_BUILD_ID="%s"' % sid, '-DNRLDPC_KERNEL_ID="%s"' % kernel_id()] if f == "nrldpc_capi.hip" else
+             ["-DNRLDPC_Z64I_FORCE_MODE=7"] if (ALLMODES and f == "nrldpc_decode.hip") else [])
              for f in SOURCES]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d.o" % (bg, z)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z]) for bg, z in Z64_PAIRS]
@@ -159,7 +164,7 @@ def build_lib(force=False, verbose=False, jobs=None):
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64P_ROW=1", "-DNRLDPC_Z64P_RW=%d" % rw]) for bg, z, rw in Z64PR]
     units += [(os.path.join(CSRC, Z64P_SOURCE), os.path.join(OBJDIR, "z64i_%d_%d.o" % (bg, z)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % (z * ncw), "-DNRLDPC_Z64_ILV=%d" % ncw, "-DNRLDPC_Z64I_ZR=%d" % z,
-                "-DNRLDPC_Z64S_DUAL=0", "-DNRLDPC_Z64I_MODE=%d" % mode]) for bg, z, ncw, mode in Z64I]
+                "-DNRLDPC_Z64S_DUAL=0", "-DNRLDPC_Z64I_MODE=%d" % (7 if ALLMODES else mode)]) for bg, z, ncw, mode in Z64I]
     units += [(os.path.join(CSRC, Z64_SOURCE), os.path.join(OBJDIR, "z64_%d_%d_nl%d.o" % (bg, z, nl)),
                ["-DNRLDPC_Z64_BG=%d" % bg, "-DNRLDPC_Z64_Z=%d" % z, "-DNRLDPC_Z64_NL=%d" % nl]) for bg, z, nl in Z64_NL]
     # every decoder unit gets a name space of its own for the -D-dependent templates (NRLDPC_UNIT, nrldpc_decode_z64.h)

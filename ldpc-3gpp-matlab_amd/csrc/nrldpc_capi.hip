@@ -358,6 +358,9 @@ struct nrldpc_codec {
     // last_layers = what the last call ran with; rule_auto: cfg.alpha == 0, the check-node rule follows the count in use
     int layers = 0, last_layers = 0, rule_layers = 0;
     bool rule_auto = false;
+    // batch counters of the parity-stop kernels that refill their codeword slots (DecArgs::work): a ring, one per launch in flight
+    DevBuf<int32_t> d_work;
+    unsigned work_seq = 0;
     DevBuf<int32_t> d_best; // NRLDPC_LAYERS_AUTO on device pointers: the pre-pass kernel's result ...
     PinBuf pin_best;        // ... and where the host reads it
     // device tables
@@ -514,11 +517,19 @@ int resolve_layers_dev(nrldpc_codec* h, const void* d_llr, int batch, hipStream_
     return NRLDPC_OK;
 }
 
+// the batch counter of the next launch (null when the ring cannot be allocated: the kernels then run without refilling)
+int32_t* next_work(nrldpc_codec* h) {
+    constexpr unsigned RING = 64;
+    if (h->d_work.reserve(RING) != hipSuccess) return nullptr;
+    return h->d_work.p + (h->work_seq++ % RING);
+}
+
 int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters, float* d_app,
                   hipStream_t stream, int nl, int llr_kind = -1) {
     const nrldpc::Schedule& s = h->sched;
-    const nrldpc::DecArgs a = make_dec_args(h, d_llr, batch, d_hard, d_iters, d_app, nl, llr_kind);
+    nrldpc::DecArgs a = make_dec_args(h, d_llr, batch, d_hard, d_iters, d_app, nl, llr_kind);
     h->last_layers = nl;
+    a.work = next_work(h);
     begin_timing(h, stream);
     hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, stream);
     end_timing(h, stream);
@@ -693,7 +704,7 @@ int nrldpc_create(const nrldpc_cfg* cfg_in, nrldpc_handle* out) {
 void nrldpc_destroy(nrldpc_handle h) {
     if (!h) return;
     DeviceScope scope(h->cfg.device_id);
-    h->d_rot.release(); h->d_crc.release(); h->d_best.release(); h->pin_best.release();
+    h->d_rot.release(); h->d_crc.release(); h->d_best.release(); h->pin_best.release(); h->d_work.release();
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
     h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_pk.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
@@ -906,8 +917,9 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     for (size_t r = 0; r < routed.size() && rc == NRLDPC_OK; ++r) {
         const int i = routed[r];
         nrldpc_codec* h = hs[i];
-        const nrldpc::DecArgs a = make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr, nls[i]);
+        nrldpc::DecArgs a = make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr, nls[i]);
         h->last_layers = nls[i];
+        a.work = next_work(h);
         hipError_t e = nrldpc::launch_decode(h->sched.g.bg, a, h->sched.threads, h->sched.lds_bytes, next_stream());
         if (e != hipSuccess) rc = hipfail(e, "decode kernel launch");
     }

@@ -376,7 +376,11 @@ hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes
     static const bool no_ilv = getenv("NRLDPC_NO_ILV") != nullptr;
     if (!force_generic && !no_ilv && !a.app && !crc) {
         const int want = !a.early_term ? 1 : a.n_layers == (bg == 1 ? BGT<1>::ROWS : BGT<2>::ROWS) ? 2 : 4;
+#ifdef NRLDPC_Z64I_FORCE_MODE // the experiment build (build.py: NRLDPC_BUILD_ALLMODES): every entry serves these modes, whatever the list says
+#define NRLDPC_Z64I_CASE(b, z, ncw, mode) if (bg == b && a.Z == z && ((NRLDPC_Z64I_FORCE_MODE) & want)) return launch_decode_z64i_##b##_##z(a, stream);
+#else
 #define NRLDPC_Z64I_CASE(b, z, ncw, mode) if (bg == b && a.Z == z && ((mode) & want)) return launch_decode_z64i_##b##_##z(a, stream);
+#endif
         NRLDPC_Z64I_LIST(NRLDPC_Z64I_CASE)
 #undef NRLDPC_Z64I_CASE
     }

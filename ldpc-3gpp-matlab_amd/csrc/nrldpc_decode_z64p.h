@@ -30,7 +30,10 @@ template <int BG, int ZC, int NL = BGT<BG>::ROWS> struct Z64P : Z64<BG, ZC, 1, N
     // Interleaved block geometry: the extension-column channel LLRs live in LDS behind the flags, one int8 per extension row and
     // row lane ([row][lane] bytes, as in the split kernels of the block geometry: DecStateS, Z64S::XL), where that does not
     // cost a workgroup per CU -- without them the parity-stop build spills 130 registers at 80 VGPRs
-    static constexpr size_t XOFF = FLAGS + 4 * (size_t)((NCW + 1 + 3) / 4 * 4);
+    // flags: [NCW] "slot c's codeword has a violated check", "some slot goes on", "some slot took a new codeword"; then the slots of
+    // the parity-stop builds: [NCW] codeword index, [NCW] iterations it has had (nrldpc_decode_z64p_kernel)
+    static constexpr int SLOT0 = (NCW + 2 + 3) / 4 * 4;
+    static constexpr size_t XOFF = FLAGS + 4 * (size_t)((SLOT0 + 2 * NCW + 3) / 4 * 4);
     static constexpr size_t XBYTES = (size_t)(B::NLT - 4) * ZC;
     static constexpr int wgs_per_cu(size_t lds) {
         const int by_waves = 24 / (2 * RW) > 0 ? 24 / (2 * RW) : 1, by_lds = (int)((160 * 1024) / lds);
@@ -95,51 +98,11 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
             asm volatile("" : "+v"(R[1]));
         }
     }
-    const uint32_t home0 = (uint32_t)G::GUARD + 4u * (uint32_t)g; // this thread's word of column 0's ring
-    const size_t base = (size_t)(present ? cw : 0) * ncwz;
-
-    // ---- core columns -> LDS (ring and mirror), the halves take alternate columns; raw bits first, conversions after
-    {
-        auto ingest_as = [&](auto kind_c) {
-            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
-            constexpr int NPU = (G::NC + 1) / 2;
-            uint32_t x[NPU];
-            static_for<NPU>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const int col = 2 * k + half;
-                x[k] = 0u;
-                if (present && (2 * k + 1 < G::NC || col < G::NC)) {
-                    if constexpr (F16) x[k] = static_cast<const uint16_t*>(a.llr)[base + (size_t)col * ZR + z];
-                    else x[k] = static_cast<const uint32_t*>(a.llr)[base + (size_t)col * ZR + z];
-                }
-            });
-            static_for<NPU>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const int col = 2 * k + half;
-                if (2 * k + 1 < G::NC || col < G::NC) {
-                    float v;
-                    if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)x[k]));
-                    else v = __uint_as_float(x[k]);
-                    const float q = present ? ingest(v, a.scale, true) : 0.0f;
-                    char* home = lds + home0 + col * G::CS;
-                    *reinterpret_cast<float*>(home) = q;
-                    if constexpr (G::ILVM) {
-                        if (g < G::BLK) *reinterpret_cast<float*>(home + 4 * ZC) = q; // mirror of ring block 0
-                    } else {
-                        *reinterpret_cast<float*>(home + 4 * G::NROW) = q;
-                    }
-                }
-            });
-        };
-        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
-        else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
-    }
-
-    // hard decisions of this thread's columns of its codeword (the halves take alternate columns) + the iteration count
-    // Where this thread sits, derived AGAIN from the thread id through an opaque copy: the parity pass and the write-back need the
-    // codeword index and the row position once per iteration at most, and values computed before the iteration loop and used
-    // only there would stay live across it -- at 80 VGPRs the compiler parks them in scratch (as in the block geometry's kernel).
-    struct Where { int half, g, z, c, cw; uint32_t home0; };
+    // Where this thread sits, derived AGAIN from the thread id through an opaque copy: the parity pass, the write-back and the
+    // refill need the codeword slot and the row position once per iteration at most, and values computed before the iteration loop
+    // and used only there would stay live across it -- at 80 VGPRs the compiler parks them in scratch (as in the block geometry's
+    // kernel).
+    struct Where { int half, g, z, c; uint32_t home0; };
     auto where = [&]() {
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
@@ -149,20 +112,74 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
         p.g = G::ILVM ? (wv % G::RW) * G::BLK + ln : (wv % G::RW) * 64 + ln;
         p.z = p.g / G::NCW;
         p.c = p.g - p.z * G::NCW;
-        p.cw = blockIdx.x * G::NCW + p.c;
         p.home0 = (uint32_t)G::GUARD + 4u * (uint32_t)p.g;
         return p;
     };
-    auto write_out = [&](int it) {
-        const Where p = where();
-        uint8_t* hard = a.hard + (size_t)p.cw * ((size_t)G::KB * ZR) + p.z;
+
+    // ---- core columns of codeword `cwi` -> LDS (ring and mirror), by the lanes with `wr` set (the prologue: every lane; a refill:
+    // the lanes of the slots that take a new codeword); have = the codeword exists (else zeros: the lane decodes nothing).  The
+    // halves take alternate columns; raw bits first, conversions after
+    auto load_core = [&](const Where& p, bool wr, bool have, int cwi) {
+        const size_t base = (size_t)(have ? cwi : 0) * ncwz;
+        auto ingest_as = [&](auto kind_c) {
+            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
+            constexpr int NPU = (G::NC + 1) / 2;
+            uint32_t x[NPU];
+            static_for<NPU>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int col = 2 * k + p.half;
+                x[k] = 0u;
+                if (wr && have && (2 * k + 1 < G::NC || col < G::NC)) {
+                    if constexpr (F16) x[k] = static_cast<const uint16_t*>(a.llr)[base + (size_t)col * ZR + p.z];
+                    else x[k] = static_cast<const uint32_t*>(a.llr)[base + (size_t)col * ZR + p.z];
+                }
+            });
+            static_for<NPU>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int col = 2 * k + p.half;
+                if (wr && (2 * k + 1 < G::NC || col < G::NC)) {
+                    float v;
+                    if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)x[k]));
+                    else v = __uint_as_float(x[k]);
+                    const float q = have ? ingest(v, a.scale, true) : 0.0f;
+                    char* home = lds + p.home0 + col * G::CS;
+                    *reinterpret_cast<float*>(home) = q;
+                    if constexpr (G::ILVM) {
+                        if (p.g < G::BLK) *reinterpret_cast<float*>(home + 4 * ZC) = q; // mirror of ring block 0
+                    } else {
+                        *reinterpret_cast<float*>(home + 4 * G::NROW) = q;
+                    }
+                }
+            });
+        };
+        if (a.llr_kind == NRLDPC_K_F16) ingest_as(std::integral_constant<int, NRLDPC_K_F16>{});
+        else ingest_as(std::integral_constant<int, NRLDPC_K_F32>{});
+    };
+    {
+        Where p0;
+        p0.half = half; p0.g = g; p0.z = z; p0.c = c; p0.home0 = (uint32_t)G::GUARD + 4u * (uint32_t)g;
+        load_core(p0, true, present, cw);
+    }
+    // Parity-stop builds: a workgroup's NCW codeword SLOTS, each with the index of the codeword it holds and the iterations that one
+    // has had (LDS words behind the flags).  A slot whose codeword is finished -- its checks hold, or it has had max_iter iterations --
+    // writes its result and takes the next codeword of the batch from a counter in device memory (DecArgs::work); the other slots
+    // keep their messages and go on.  Until round 4 a workgroup lived until the LAST of its NCW codewords stopped.
+    int* slot_cw = flags + G::SLOT0;
+    int* slot_it = slot_cw + G::NCW;
+    if constexpr (ETP) {
+        if (half == 0 && z == 0) { slot_cw[c] = present ? cw : a.batch; slot_it[c] = 0; }
+    }
+
+    // hard decisions of this thread's columns of codeword `cwi` (the halves take alternate columns) + the iteration count
+    auto write_out = [&](const Where& p, int cwi, int it) {
+        uint8_t* hard = a.hard + (size_t)cwi * ((size_t)G::KB * ZR) + p.z;
         static_for<(G::KB + 1) / 2>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const int col = 2 * k + p.half;
             if (2 * k + 1 < G::KB || col < G::KB)
                 hard[(size_t)col * ZR] = *reinterpret_cast<const float*>(lds + p.home0 + col * G::CS) < 0.0f ? 1 : 0;
         });
-        if (a.iters && p.z == 0 && p.half == 0) a.iters[p.cw] = it;
+        if (a.iters && p.z == 0 && p.half == 0) a.iters[cwi] = it;
     };
 
     auto run = [&](auto hc) {
@@ -177,37 +194,42 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
 #pragma unroll
             for (int i = 0; i < O::NXW; ++i) st.xq[i] = 0;
         }
-        auto load_ext = [&](auto kind_c) {
-            constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
-            uint32_t xe[O::NEXT > 0 ? O::NEXT : 1];
-            // (run-time layer count: pruned rows' extension LLRs are never used and never loaded, in blocks of 8 rows)
-            static_for<(G::NLT - 4 + 7) / 8>([&](auto bc) {
-                constexpr int L0 = 4 + 8 * decltype(bc)::value;
-                constexpr int L1 = L0 + 8 < G::NLT ? L0 + 8 : G::NLT;
-                const bool used = present && (!G::RT || L0 < launder(a.n_layers));
-                static_for<L1 - L0>([&](auto ic) {
-                    constexpr int L = L0 + decltype(ic)::value;
-                    if constexpr (O::mine(L)) {
-                        constexpr int xi = O::ext_index(L);
-                        const size_t i = base + (size_t)(G::NC + L - 4) * ZR + z;
-                        xe[xi] = 0u;
-                        if (used) {
-                            if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
-                            else xe[xi] = static_cast<const uint32_t*>(a.llr)[i];
+        // extension LLRs of this half's rows of codeword `cwi`, by the lanes with `wr` set (see load_core)
+        auto load_ext = [&](int zz, bool wr, bool have, int cwi) {
+            const size_t base = (size_t)(have ? cwi : 0) * ncwz;
+            auto as = [&](auto kind_c) {
+                constexpr bool F16 = decltype(kind_c)::value == NRLDPC_K_F16;
+                uint32_t xe[O::NEXT > 0 ? O::NEXT : 1];
+                // (run-time layer count: pruned rows' extension LLRs are never used and never loaded, in blocks of 8 rows)
+                static_for<(G::NLT - 4 + 7) / 8>([&](auto bc) {
+                    constexpr int L0 = 4 + 8 * decltype(bc)::value;
+                    constexpr int L1 = L0 + 8 < G::NLT ? L0 + 8 : G::NLT;
+                    const bool used = wr && have && (!G::RT || L0 < launder(a.n_layers));
+                    static_for<L1 - L0>([&](auto ic) {
+                        constexpr int L = L0 + decltype(ic)::value;
+                        if constexpr (O::mine(L)) {
+                            constexpr int xi = O::ext_index(L);
+                            const size_t i = base + (size_t)(G::NC + L - 4) * ZR + zz;
+                            xe[xi] = 0u;
+                            if (used) {
+                                if constexpr (F16) xe[xi] = static_cast<const uint16_t*>(a.llr)[i];
+                                else xe[xi] = static_cast<const uint32_t*>(a.llr)[i];
+                            }
                         }
-                    }
+                    });
                 });
-            });
-            static_for<O::NEXT>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                float v;
-                if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)xe[i]));
-                else v = __uint_as_float(xe[i]);
-                st.template set_ext<i>(present ? ingest(v, a.scale, false) : 0.0f);
-            });
+                static_for<O::NEXT>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    float v;
+                    if constexpr (F16) v = __half2float(__ushort_as_half((unsigned short)xe[i]));
+                    else v = __uint_as_float(xe[i]);
+                    if (wr) st.template set_ext<i>(have ? ingest(v, a.scale, false) : 0.0f);
+                });
+            };
+            if (a.llr_kind == NRLDPC_K_F16) as(std::integral_constant<int, NRLDPC_K_F16>{});
+            else as(std::integral_constant<int, NRLDPC_K_F32>{});
         };
-        if (a.llr_kind == NRLDPC_K_F16) load_ext(std::integral_constant<int, NRLDPC_K_F16>{});
-        else load_ext(std::integral_constant<int, NRLDPC_K_F32>{});
+        load_ext(z, true, present, cw);
         __syncthreads(); // the a-posteriori rings are complete
         const float cap = (127.49f + a.beta) / a.alpha; // see LayerZ64::track3
         DecArgs av = a;
@@ -216,13 +238,13 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
         asm volatile("" : "+v"(av.alpha), "+v"(av.beta));
 #endif
         uint32_t esign_lo = 0, esign_hi = 0;
-        bool done = !present; // per lane (= per codeword: both halves read the same flags)
         GroupZ64<BG, ZC, 0, NL, H> g0;
         if constexpr (H == 0) {
             g0.template loads<false>(lds, R);
             g0.template track<false, XF>(st, cap);
         }
-        for (int it = 1; it <= a.max_iter; ++it) {
+        // one iteration over the active layers (the halves alternate barrier groups: nrldpc_decode_z64s.h)
+        auto iteration = [&]() {
             if constexpr (ETP) { esign_lo = 0; esign_hi = 0; }
             if constexpr (H == 0) {
                 GroupZ64<BG, ZC, 0, NL, H> nx;
@@ -235,19 +257,30 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
             } else {
                 s_early<BG, ZC, NL, H, ETP, XF, 0>(g0, st, lds, R, RA, RB, rw, av, cap, esign_lo, esign_hi);
             }
-            if constexpr (ETP) {
-                // parity check of this half's rows, per codeword: flags[c] = "codeword c has a violated check",
-                // flags[NCW] = "a codeword that had not converged before still has one"
-                // (raw thread ids: the lanes >= BLK of a wave have retired, so the NCW + 1 flags must fit below BLK)
-                static_assert(!G::ILVM || G::BLK == 64 || G::NCW + 1 <= G::BLK, "flags are cleared by raw thread id: lanes >= BLK have retired");
-                if ((int)threadIdx.x <= G::NCW) flags[threadIdx.x] = 0;
+        };
+        if constexpr (!ETP) {
+            for (int it = 1; it <= a.max_iter; ++it) iteration();
+            __syncthreads(); // the last group's writes
+            if (present) write_out(where(), cw, a.max_iter);
+        } else {
+            for (;;) {
+                iteration();
+                // parity check of this half's rows, per slot: flags[c] = "the codeword in slot c has a violated check",
+                // flags[NCW] = "some slot goes on", flags[NCW + 1] = "some slot took a new codeword"
+                // (raw thread ids: the lanes >= BLK of a wave have retired, so the NCW + 2 flags must fit below BLK)
+                static_assert(!G::ILVM || G::BLK == 64 || G::NCW + 2 <= G::BLK, "flags are cleared by raw thread id: lanes >= BLK have retired");
+                if ((int)threadIdx.x <= G::NCW + 1) flags[threadIdx.x] = 0;
                 __syncthreads();
-                const int c = where().c; // (this shadows the prologue's copy on purpose: see `where`)
+                const Where p = where();
+                const int c = p.c;                      // (this shadows the prologue's copy on purpose: see `where`)
+                const int cwi = slot_cw[c];             // the slot's codeword and the iterations it has had, this one included
+                const int iti = slot_it[c] + 1;
+                const bool empty = cwi >= a.batch;      // the batch is exhausted: the slot's lanes decode nothing anybody reads
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform: every lane's codeword is settled (violated, or out of the vote)
                 auto vote = [&]() {
-                    if (bad && !done) flags[c] = 1;
-                    stop = __all((int)(bad | (uint32_t)done | (uint32_t)__atomic_load_n(&flags[c], __ATOMIC_RELAXED))) != 0;
+                    if (bad && !empty) flags[c] = 1;
+                    stop = __all((int)(bad | (uint32_t)empty | (uint32_t)__atomic_load_n(&flags[c], __ATOMIC_RELAXED))) != 0;
                 };
                 if constexpr (G::RT) { // run-time layer count: highest row first, pruned rows skipped eight at a time (Own::parity_order_desc)
                     constexpr auto PD = O::parity_order_desc();
@@ -275,36 +308,88 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                         if constexpr (i < 3 || (i % 4) == 3 || i + 1 == PO.n || O::ncore(L) > 10 || (i + 1 < PO.n && O::ncore(PO.v[i + 1 < PO.n ? i + 1 : i]) > 10)) vote();
                     }
                 });
-                if (bad && !done) { flags[c] = 1; flags[G::NCW] = 1; }
+                if (bad && !empty) flags[c] = 1;
                 __syncthreads();
-                if (!done && flags[c] == 0) { // converged at this iteration: its result leaves now
-                    done = true;
-                    write_out(it);
+                // a finished codeword's result leaves now, by its own lanes ...
+                const bool fin = !empty && (flags[c] == 0 || iti >= a.max_iter);
+                if (fin) write_out(p, cwi, iti);
+                // ... and the slot's first lane of half 0 takes the next codeword of the batch (or none: the slot stays empty)
+                if (p.half == 0 && p.z == 0) {
+                    if (fin) {
+                        int nxt = a.batch;
+                        if (a.work) nxt = atomicAdd(a.work, 1);
+                        if (nxt >= a.batch) nxt = a.batch;
+                        slot_cw[c] = nxt;
+                        slot_it[c] = 0;
+                        if (nxt < a.batch) { flags[G::NCW] = 1; flags[G::NCW + 1] = 1; }
+                    } else if (!empty) {
+                        slot_it[c] = iti;
+                        flags[G::NCW] = 1;
+                    }
                 }
-                if (__builtin_amdgcn_readfirstlane(flags[G::NCW]) == 0) break; // nobody is left
+                __syncthreads();
+                if (__builtin_amdgcn_readfirstlane(flags[G::NCW]) == 0) break; // every slot is empty
+                if (__builtin_amdgcn_readfirstlane(flags[G::NCW + 1]) != 0) {  // some slot starts a new codeword: its lanes load it
+                    const Where q = where();
+                    const int nw = slot_cw[q.c];
+                    const bool refill = fin && nw < a.batch;
+                    if (__any((int)refill)) {
+                        load_core(q, refill, true, nw);
+                        load_ext(q.z, refill, true, nw);
+                        if (refill) {
+#pragma unroll
+                            for (int i = 0; i < O::NW; ++i) st.rm[i] = 0;
+                        }
+                    }
+                    __syncthreads(); // the new codewords' rings are complete
+                    if constexpr (H == 0) { // group 0's early part again: it was read before the refill
+                        g0.template loads<false>(lds, R);
+                        g0.template track<false, XF>(st, cap);
+                    }
+                }
             }
         }
-        if constexpr (!ETP) __syncthreads(); // the last group's writes
-        if (!done) write_out(a.max_iter);
     };
     if (half == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
 }
 
+// Workgroups of one launch.  Parity-stop builds refill their slots from the batch, so a launch of them is PERSISTENT: as many
+// workgroups as the device holds at once (occupancy x compute units, asked of the runtime once per kernel and device) when the
+// batch has more codewords than those hold, each starting with NCW codewords and pulling the rest through DecArgs::work, which
+// this function sets to the first index nobody starts with.  Fixed-iteration builds: one workgroup per NCW codewords, as before.
 template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t launch_z64p_t(const DecArgs& a, hipStream_t s) {
     using G = Z64P<BG, ZC, NL>;
     auto k = nrldpc_decode_z64p_kernel<BG, ZC, ETP, NL, (z64_ilvm() ? 1000 + z64_ilv() : 0)>;
     constexpr size_t lds = G::lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {};
+    static int resident[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), G::THREADS, lds) != hipSuccess) per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        resident[dev & 63] = per_cu * cus;
         attr_set[dev & 63] = true;
     }
-    hipLaunchKernelGGL(k, dim3((a.batch + G::NCW - 1) / G::NCW), dim3(G::THREADS), lds, s, a);
+    int grid = (a.batch + G::NCW - 1) / G::NCW;
+    DecArgs b = a;
+    static const bool no_refill = getenv("NRLDPC_NO_REFILL") != nullptr; // A/B: every workgroup decodes its own NCW codewords and leaves
+    // NRLDPC_REFILL_GRID=<n>: at most n workgroups per launch (tests: a small batch then goes through the refill path; read per call)
+    int cap = resident[dev & 63];
+    if (const char* e = getenv("NRLDPC_REFILL_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+    if (ETP && a.work && !no_refill && cap > 0 && grid > cap) {
+        grid = cap;
+        hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.work), grid * G::NCW, 1, s);
+        if (e != hipSuccess) return e;
+    } else {
+        b.work = nullptr;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(G::THREADS), lds, s, b);
     return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@
 #include "nrldpc_host_quant.h"
 
 #include <math.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 #if defined(__x86_64__)
@@ -153,12 +154,51 @@ template <class U> bool any_set(const U* p, size_t n) {
     }
     return false;
 }
+// The scan's bulk is blocks that ARE all zero (what rate matching left untransmitted): those are settled by OR-ing the words
+// together with the sign bits masked off -- no compares, one pass at memory speed (the first build compared element by element
+// with baseline-x86-64 code: 516 MB of zeros took 9 ms on the MI355X box's host, longer than quantising the whole batch).  Only a
+// block whose OR is not zero is looked at value by value (it may hold nothing but NaNs).
+template <class U> static inline bool or_is_zero_body(const U* p, size_t n) {
+    constexpr uint64_t M = sizeof(U) == 8 ? 0x7fffffffffffffffull : sizeof(U) == 4 ? 0x7fffffff7fffffffull : 0x7fff7fff7fff7fffull;
+    const char* b = reinterpret_cast<const char*>(p);
+    const size_t bytes = n * sizeof(U);
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    size_t i = 0;
+    for (; i + 64 <= bytes; i += 64) {
+        uint64_t w[8];
+        memcpy(w, b + i, 64);
+        a0 |= w[0]; a1 |= w[1]; a2 |= w[2]; a3 |= w[3]; a4 |= w[4]; a5 |= w[5]; a6 |= w[6]; a7 |= w[7];
+    }
+    uint64_t acc = (a0 | a1 | a2 | a3 | a4 | a5 | a6 | a7) & M;
+    for (; i + sizeof(U) <= bytes; i += sizeof(U)) {
+        U v;
+        memcpy(&v, b + i, sizeof(U));
+        acc |= (uint64_t)(v & Bits<U>::ABS);
+    }
+    return acc == 0;
+}
+#if defined(__x86_64__)
+template <class U> __attribute__((target("avx2"))) static bool or_is_zero_avx2(const U* p, size_t n) { return or_is_zero_body(p, n); }
+#endif
+template <class U> static bool or_is_zero(const U* p, size_t n) {
+#if defined(__x86_64__)
+    static const bool has = __builtin_cpu_supports("avx2");
+    if (has) return or_is_zero_avx2(p, n);
+#endif
+    return or_is_zero_body(p, n);
+}
+
 template <class U> void top_block(const U* src, size_t n_total, size_t cw0, size_t cw_step, int Z, int nblocks, int first, int* best) {
     for (size_t cw = cw0; cw < n_total; cw += cw_step) {
         const U* base = src + cw * (size_t)nblocks * (size_t)Z;
+        // the usual case first -- every codeword of a call was rate-matched alike, so nothing lies above what an earlier codeword
+        // found: one ASCENDING pass over the whole tail (block by block from the top the hardware prefetcher restarts every Z values)
+        const int lo = std::max(first, __atomic_load_n(best, __ATOMIC_RELAXED) + 1);
+        if (lo >= nblocks) return;
+        if (or_is_zero(base + (size_t)lo * Z, (size_t)(nblocks - lo) * (size_t)Z)) continue;
         for (int b = nblocks - 1; b >= first; --b) {
             if (b <= __atomic_load_n(best, __ATOMIC_RELAXED)) break;
-            if (any_set(base + (size_t)b * Z, (size_t)Z)) {
+            if (!or_is_zero(base + (size_t)b * Z, (size_t)Z) && any_set(base + (size_t)b * Z, (size_t)Z)) {
                 int cur = __atomic_load_n(best, __ATOMIC_RELAXED);
                 while (cur < b && !__atomic_compare_exchange_n(best, &cur, b, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
                 break;

@@ -38,6 +38,9 @@ struct DecArgs {
     int32_t crc_bits;
     float alpha, scale, inv_scale;
     float beta;          // offset in grid units: message magnitude = clamp(rint(alpha*m - beta), 0, 127)
+    // one int of device memory per launch in flight (the handle's ring of them): the batch counter of the parity-stop kernels that
+    // refill their codeword slots (nrldpc_decode_z64p.h); null = none (every workgroup decodes its own codewords and leaves)
+    int32_t* work;
 };
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream);

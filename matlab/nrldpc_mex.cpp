@@ -14,7 +14,10 @@
 //                  data, exact for any rv_id / HARQ state (include/nrldpc.h "Active layers"; at plot_BLER_vs_SNR.m's defaults 21 of
 //                  BG2's 42 rows, at R = 8/9 5 of BG1's 46); 0 = every row of H, as the reference decodes (NRLDPCDecoder.m:120);
 //                  alpha 0 / omitted = the library's rate-dependent check-node rule (nrldpc_default_rule)
-//   [c_hat, it, nl] = nrldpc_mex('decode', id, cw_tilde)   cw_tilde: (N+2*Z_c) x C double OR single, +inf fillers, 0 punctured
+//   [c_hat, it, nl] = nrldpc_mex('decode', id, cw_tilde [, n_layers])   cw_tilde: (N+2*Z_c) x C double OR single, +inf fillers, 0 punctured;
+//                                                       n_layers: the count of THIS call (a caller that knows its rate -- E_r, k_0,
+//                                                       N_cb of NRLDPC.m:463-543 -- saves the scan AUTO makes: with MATLAB doubles the
+//                                                       host side is bound by reading the array, and the scan reads the zeros once)
 //                                                       c_hat: K x C double in {0,1}; it: C x 1 int32 iterations run;
 //                                                       nl: the layer count the call ran with
 //   nrldpc_mex('set_layers', id, n_layers)              the count of the calls that follow (0 all, 4..rows, -1 auto)
@@ -99,9 +102,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         g_handles[g_next] = h;
         plhs[0] = mxCreateDoubleScalar((double)g_next++);
     } else if (!strcmp(cmd, "decode")) {
-        need(nrhs == 3 && (mxIsDouble(prhs[2]) || mxIsSingle(prhs[2])) && !mxIsComplex(prhs[2]),
-             "decode needs a handle and a real double or single matrix.");
+        need((nrhs == 3 || nrhs == 4) && (mxIsDouble(prhs[2]) || mxIsSingle(prhs[2])) && !mxIsComplex(prhs[2]),
+             "decode needs a handle and a real double or single matrix [and a layer count].");
         nrldpc_handle h = handle_of(prhs[1]);
+        if (nrhs == 4) check(nrldpc_set_layers(h, (int32_t)mxGetScalar(prhs[3])));
         nrldpc_dims d;
         d.struct_size = sizeof d;
         check(nrldpc_get_dims(h, &d));

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import BG_DIMS, awgn_llr, rule_kw
-from test_decode_gpu import RT_GRID_NL, RT_GRID_Z, _waterfall_esn0
+from test_decode_gpu import _waterfall_esn0
 
 pytestmark = pytest.mark.gpu
 AUTO = -1
@@ -32,8 +32,14 @@ def dev_decode(codec, llr, dt):
     return d_h.cpu().numpy(), d_it.cpu().numpy()
 
 
+# one size per kernel family of test_run_time_layer_count_grid's grid (interleaved / packed / split / row / run-time-Z), and the
+# counts around which the check-node rule changes (nrldpc_default_rule) plus the call whose count one codeword lifts (8)
+LAYER_Z = (8, 20, 64, 96, 144, 208, 352, 384)
+LAYER_NL = (4, 8, 13, 24)
+
+
 @pytest.mark.parametrize("bg", [1, 2])
-@pytest.mark.parametrize("Z", RT_GRID_Z)
+@pytest.mark.parametrize("Z", LAYER_Z)
 def test_auto_equals_explicit_on_the_layer_count_grid(pkg, orc, bg, Z):
     """test_run_time_layer_count_grid's grid: ONE handle created under AUTO; per count, LLRs whose columns above the count are
     zero (what rate matching leaves, NRLDPCDecoder.m:216-234); the AUTO call through host and device pointers, then
@@ -47,7 +53,7 @@ def test_auto_equals_explicit_on_the_layer_count_grid(pkg, orc, bg, Z):
     cf = pkg.Codec(bg, Z, max_iter=6, n_layers=AUTO, early_term=False, llr_dtype=dt)
     assert c.n_layers == AUTO
     try:
-        for nl in RT_GRID_NL + (rows - 1, rows):
+        for nl in LAYER_NL + (rows - 1, rows):
             info = rng.integers(0, 2, (B, kb * Z), dtype=np.uint8)
             llr = awgn_llr(rng, orc.encode(bg, Z, info), _waterfall_esn0(bg, nl) + 0.2, dt, Z, E=(kb + nl - 2) * Z)
             if nl == 8:  # the count is that of the WHOLE call: one codeword reaching higher lifts everybody; NaN and -0 do not count
