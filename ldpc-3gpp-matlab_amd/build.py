@@ -37,22 +37,22 @@ Z64P_PAIRS = [(1, z) for z in Z64P_BG1] + [(2, z) for z in Z64P_BG2]
 Z64P_NL = [(2, 20, 12)]
 # = NRLDPC_Z64PR_LIST: (BG, Z, row waves) with pipelined one-thread-per-row builds in the packed geometry
 Z64PR = []  # (measured slower than the block-geometry kernels for BG2 88 ... 352: nrldpc_kernels.h)
-# = NRLDPC_Z64I_LIST: (BG, Zr, NCW, mode): the interleaved block geometry -- NCW codewords of the lifting size Zr in one workgroup
+# = NRLDPC_Z64I_LIST (nrldpc_dispatch_lists.h): (BG, Zr, NCW, mode): the interleaved block geometry -- NCW codewords of the lifting size Zr in one workgroup
 # of the block geometry of the virtual size Zr * NCW; mode = what the unit serves (and is compiled for): 1 fixed iteration
 # counts, 2 the parity stop with every row active, 4 the parity stop with pruned rows
 Z64I = [
-    (1, 2, 128, 5), (1, 3, 128, 5), (1, 4, 64, 5), (1, 5, 48, 5), (1, 6, 64, 5), (1, 7, 32, 5), (1, 8, 32, 7), (1, 9, 28, 5), (1, 10, 24, 1), (1, 11, 20, 1),
-    (1, 12, 32, 1), (1, 13, 16, 1), (1, 14, 16, 1), (1, 15, 16, 1), (1, 16, 16, 5), (1, 18, 14, 1), (1, 20, 12, 1), (1, 22, 10, 1), (1, 24, 16, 1), (1, 26, 8, 1),
-    (1, 28, 8, 1), (1, 30, 8, 1), (1, 32, 8, 1), (1, 36, 7, 7), (1, 40, 6, 1), (1, 44, 5, 7), (1, 48, 8, 1), (1, 52, 4, 1), (1, 56, 4, 1), (1, 60, 4, 1),
-    (1, 64, 4, 1), (1, 72, 5, 1), (1, 80, 3, 7), (1, 96, 4, 7), (1, 104, 2, 1), (1, 112, 2, 1), (1, 120, 2, 1), (1, 128, 2, 1), (1, 160, 1, 6), (1, 192, 2, 1),
-    (2, 2, 128, 5), (2, 4, 64, 5), (2, 5, 48, 5), (2, 7, 32, 4), (2, 8, 32, 5), (2, 9, 28, 5), (2, 10, 24, 1), (2, 11, 20, 1), (2, 13, 16, 1), (2, 14, 16, 5),
-    (2, 15, 16, 1), (2, 16, 16, 1), (2, 18, 14, 1), (2, 20, 12, 1), (2, 22, 10, 1), (2, 26, 8, 1), (2, 28, 8, 1), (2, 30, 8, 1), (2, 32, 8, 1), (2, 36, 7, 3),
-    (2, 40, 6, 1), (2, 44, 5, 7), (2, 52, 4, 1), (2, 56, 4, 1), (2, 60, 4, 1), (2, 64, 4, 1), (2, 80, 3, 7), (2, 88, 5, 1), (2, 96, 4, 1), (2, 104, 2, 1),
-    (2, 112, 2, 1), (2, 120, 2, 1), (2, 128, 2, 1), (2, 160, 3, 1), (2, 176, 1, 5),
+    (1, 2, 128, 5), (1, 3, 128, 7), (1, 4, 64, 5), (1, 5, 48, 7), (1, 6, 64, 7), (1, 7, 32, 5), (1, 8, 32, 5), (1, 9, 28, 5), (1, 10, 24, 5), (1, 11, 20, 5),
+    (1, 12, 32, 1), (1, 13, 16, 1), (1, 14, 16, 1), (1, 15, 16, 1), (1, 16, 16, 5), (1, 18, 14, 5), (1, 20, 12, 1), (1, 22, 10, 1), (1, 24, 16, 1),
+    (1, 26, 8, 1), (1, 28, 8, 1), (1, 30, 8, 1), (1, 32, 8, 5), (1, 36, 7, 7), (1, 40, 6, 5), (1, 44, 5, 7), (1, 48, 8, 1), (1, 52, 4, 5), (1, 56, 4, 5),
+    (1, 60, 4, 7), (1, 64, 4, 7), (1, 72, 5, 1), (1, 80, 3, 7), (1, 96, 4, 7), (1, 104, 2, 7), (1, 112, 2, 3), (1, 120, 2, 3), (1, 128, 2, 7), (1, 160, 1, 6),
+    (1, 192, 2, 1), (2, 2, 128, 3), (2, 4, 64, 7), (2, 5, 48, 7), (2, 7, 32, 6), (2, 8, 32, 7), (2, 9, 28, 7), (2, 10, 24, 7), (2, 11, 20, 7), (2, 13, 16, 5),
+    (2, 14, 16, 5), (2, 15, 16, 5), (2, 16, 16, 5), (2, 18, 14, 5), (2, 20, 12, 5), (2, 22, 10, 5), (2, 26, 8, 5), (2, 28, 8, 5), (2, 30, 8, 5), (2, 32, 8, 5),
+    (2, 36, 7, 7), (2, 40, 6, 5), (2, 44, 5, 7), (2, 52, 4, 1), (2, 56, 4, 1), (2, 60, 4, 1), (2, 64, 4, 1), (2, 80, 3, 7), (2, 88, 5, 1), (2, 96, 4, 1),
+    (2, 104, 2, 1), (2, 112, 2, 1), (2, 120, 2, 1), (2, 128, 2, 1), (2, 160, 3, 1), (2, 176, 1, 1),
 ]
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7), (2, 208, 21)]
-HEADERS = ["nrldpc_kernels.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h", "nrldpc_hostpath.h"]
+HEADERS = ["nrldpc_kernels.h", "nrldpc_dispatch_lists.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h", "nrldpc_hostpath.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DNRLDPC_Z64_AB"] if AB else [])
 
 
@@ -82,7 +82,7 @@ def source_id():
 
 KERNEL_SOURCES = ["nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_decode_z64_inst.hip",
                   "nrldpc_decode_z64p_inst.hip", "nrldpc_decode.hip",
-                  "nrldpc_device.h", "nrldpc_kernels.h"]
+                  "nrldpc_device.h", "nrldpc_kernels.h", "nrldpc_dispatch_lists.h"]
 
 
 def kernel_id():

@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "nrldpc_device.h"
+#include "nrldpc_dispatch_lists.h"
 
 namespace nrldpc {
 

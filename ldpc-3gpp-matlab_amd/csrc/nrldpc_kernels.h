@@ -71,26 +71,8 @@ NRLDPC_Z64_LIST(NRLDPC_Z64_DECL)
 NRLDPC_Z64P_LIST(NRLDPC_Z64P_DECL)
 #undef NRLDPC_Z64P_DECL
 bool has_z64p_kernel(int bg, int Z, bool early_term);
-// ... and the INTERLEAVED block geometry (z64_ilv, nrldpc_decode_z64.h / nrldpc_decode_z64p.h): (BG, Zr, NCW, mode) =
-// NCW codewords of the lifting size Zr in one workgroup of the block geometry of the virtual size Zr * NCW (256, 384, 240, 224,
-// 208; 252 = 4 x 63, 220 = 4 x 55, 360, 440, 480: shapes no lifting size has).  mode = what the entry serves, and is compiled for,
-// each bit set where it beat the kernel that served the size before (tools/ab_ilv.py, profiles/r04_ilv_ab.txt): 1 fixed
-// iteration counts (any layer count), 2 the parity stop with every row active, 4 the parity stop with pruned rows -- a
-// workgroup lives until the LAST of its NCW codewords stops, so with the stop most sizes keep their previous kernels.
-// Measured and not listed: BG1 88 x 5, 144 x 3, 160 x 2 / x 3; BG2 3, 6, 12, 24, 48, 192 on the 384 shape, 72 x 5, 144 x 3; NCW = 1
-// (the lifting size itself in this kernel) for 144 ... 384 except the two entries below.
-#define NRLDPC_Z64I_LIST(X) \
-    X(1, 2, 128, 5) X(1, 3, 128, 5) X(1, 4, 64, 5) X(1, 5, 48, 5) X(1, 6, 64, 5) X(1, 7, 32, 5) X(1, 8, 32, 7) X(1, 9, 28, 5) X(1, 10, 24, 1) X(1, 11, 20, 1) \
-    X(1, 12, 32, 1) X(1, 13, 16, 1) X(1, 14, 16, 1) X(1, 15, 16, 1) X(1, 16, 16, 5) X(1, 18, 14, 1) X(1, 20, 12, 1) X(1, 22, 10, 1) X(1, 24, 16, 1) X(1, 26, 8, 1) \
-    X(1, 28, 8, 1) X(1, 30, 8, 1) X(1, 32, 8, 1) X(1, 36, 7, 7) X(1, 40, 6, 1) X(1, 44, 5, 7) X(1, 48, 8, 1) X(1, 52, 4, 1) X(1, 56, 4, 1) X(1, 60, 4, 1) \
-    X(1, 64, 4, 1) X(1, 72, 5, 1) X(1, 80, 3, 7) X(1, 96, 4, 7) X(1, 104, 2, 1) X(1, 112, 2, 1) X(1, 120, 2, 1) X(1, 128, 2, 1) X(1, 160, 1, 6) X(1, 192, 2, 1) \
-    X(2, 2, 128, 5) X(2, 4, 64, 5) X(2, 5, 48, 5) X(2, 7, 32, 4) X(2, 8, 32, 5) X(2, 9, 28, 5) X(2, 10, 24, 1) X(2, 11, 20, 1) X(2, 13, 16, 1) X(2, 14, 16, 5) \
-    X(2, 15, 16, 1) X(2, 16, 16, 1) X(2, 18, 14, 1) X(2, 20, 12, 1) X(2, 22, 10, 1) X(2, 26, 8, 1) X(2, 28, 8, 1) X(2, 30, 8, 1) X(2, 32, 8, 1) X(2, 36, 7, 3) \
-    X(2, 40, 6, 1) X(2, 44, 5, 7) X(2, 52, 4, 1) X(2, 56, 4, 1) X(2, 60, 4, 1) X(2, 64, 4, 1) X(2, 80, 3, 7) X(2, 88, 5, 1) X(2, 96, 4, 1) X(2, 104, 2, 1) \
-    X(2, 112, 2, 1) X(2, 120, 2, 1) X(2, 128, 2, 1) X(2, 160, 3, 1) X(2, 176, 1, 5)
-#define NRLDPC_Z64I_DECL(bg, z, ncw, et) hipError_t launch_decode_z64i_##bg##_##z(const DecArgs& a, hipStream_t stream);
-NRLDPC_Z64I_LIST(NRLDPC_Z64I_DECL)
-#undef NRLDPC_Z64I_DECL
+// ... and the INTERLEAVED block geometry (NRLDPC_Z64I_LIST): nrldpc_dispatch_lists.h -- a header of its own, read only by the dispatch
+// (nrldpc_decode.hip), so that a change of an entry's mode bits recompiles that entry's unit and the dispatch, not every kernel
 // ... and the packed geometry's pipelined one-thread-per-row builds (nrldpc_decode_z64p.h, MODE 1 / 2; -DNRLDPC_Z64P_ROW): (BG, Z,
 // row waves per workgroup).  EMPTY: built for BG2's large lifting sizes that do not split into full waves (88, 96, 176, 352 with
 // 6 row waves; 144, 160, 288, 320 with 5), bit-exact, and slower than the block-geometry kernels at every one of them

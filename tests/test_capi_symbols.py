@@ -183,17 +183,17 @@ def test_count_layers_is_the_definition_of_auto(pkg):
 
 
 def test_committed_profile_belongs_to_the_tree_kernels(pkg):
-    """bench.py takes its VALU instruction counts and HBM traffic from profiles/r04_* only when their nrldpc_kernel_id equals
+    """bench.py takes its VALU instruction counts and HBM traffic from profiles/r05_* only when their nrldpc_kernel_id equals
     the loaded library's (a kernel change without a profile refresh silently falsified a fraction).  This test
     makes the refresh hard to forget: the committed summaries must be those of the decoder kernels in the tree."""
     import json
     kid = pkg._capi._build.kernel_id()
     assert pkg.load().nrldpc_kernel_id().decode() == kid
-    for f in ("r04_bench_pmc_summary.json", "r04_traffic_bytes_per_launch.json", "r04_headline_isa_mix.json"):
+    for f in ("r05_bench_pmc_summary.json", "r05_traffic_bytes_per_launch.json", "r05_headline_isa_mix.json"):
         d = json.load(open(os.path.join(ROOT, "profiles", f)))
         got = d.get("_nrldpc_kernel_id") or d.get("nrldpc_kernel_id")
         assert got == kid, "%s was measured on kernels %s, the tree holds %s: re-run tools/final_session.sh" % (f, got, kid)
-    line = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
     assert line["roofline"]["profile"]["nrldpc_kernel_id"] == kid and line["roofline"]["frac"] is not None
     assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] == "valu_issue"
 
@@ -206,6 +206,7 @@ def test_kernel_lists_of_the_build_and_of_the_dispatch_agree():
     bld = importlib.import_module("ldpc-3gpp-matlab_amd.build")
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldpc-3gpp-matlab_amd", "csrc",
                             "nrldpc_kernels.h")).read().replace("\\\n", " ")
+    src += open(os.path.join(ROOT, "ldpc-3gpp-matlab_amd", "csrc", "nrldpc_dispatch_lists.h")).read().replace("\\\n", " ")
 
     def pairs(name):
         m = re.search(r"#define %s\(X\)([^\n]*)" % name, src)

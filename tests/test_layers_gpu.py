@@ -165,6 +165,16 @@ def test_auto_on_the_pipelined_host_path(pkg, orc, dt):
     c.set_layers(AUTO)                                         # ... which AUTO would not have ignored
     c.decode(junk[:8])
     assert c.last_layers() == 46
+    # the scan goes chunk by chunk (the count of the first chunk, each later chunk checked before it is sent): ONE value above that
+    # count in the last codeword of the batch makes the call start again with the count of the whole batch
+    late = llr.copy()
+    late[B - 1, 40 * Z + 7] = 0.5
+    assert pkg._capi.count_layers(bg, Z, late) == 19
+    h5, it5 = c.decode(late, want_iters=True)
+    assert c.last_layers() == 19
+    cd.set_layers(19)
+    h6, it6 = dev_decode(cd, late, dev_dt)
+    assert (h5 == h6).all() and (it5 == it6).all()
     c.close(); cd.close()
 
 

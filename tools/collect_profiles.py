@@ -10,7 +10,8 @@ pairs = [("bench_line.json", "_bench_line.json"), ("bench_configs.json", "_bench
          ("bench_host_path.json", "_bench_host_path.json"), ("bler_gap.json", "_bler_gap.json"),
          ("prof_chain/chain_kernel_stats.csv", "_chain_kernel_stats.csv"), ("prof_cfg/cfg_kernel_stats.csv", "_configs_kernel_stats.csv"),
          ("gputests.log", "_gputests.txt"), ("bench_nl.txt", "_bench_nl.txt"), ("bench_crc_stop.json", "_crc_stop.json"),
-         ("bench_cfg5_n1.json", "_bench_cfg5_n1.json"), ("host_trace.txt", "_host_trace.txt")]
+         ("bench_cfg5_n1.json", "_bench_cfg5_n1.json"), ("host_trace.txt", "_host_trace.txt"),
+         ("bench_all_z_stop.json", "_bench_all_z_stop.json"), ("bench_all_z_stop_norefill.json", "_bench_all_z_stop_norefill.json")]
 # what the box summarised in place (PMC summary, traffic, kernel stats, instruction mix) first; the session's own outputs then
 # overwrite any stale copy of themselves that travelled to the box inside profiles/
 d = os.path.join(G, "profiles_" + tag)

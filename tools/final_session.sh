@@ -1,8 +1,8 @@
 #!/bin/bash
-# The measurement set behind profiles/r04_*: GPU tests, bench line, every BASELINE configuration, all lifting sizes, chain stages
+# The measurement set behind profiles/r05_*: GPU tests, bench line, every BASELINE configuration, all lifting sizes, chain stages
 # (+ their kernel trace), Monte-Carlo loop, host path, rocprofv3 kernel trace + PMC passes of the bench command.
-# TAG=r04 bash tools/final_session.sh ; then on the build box: python tools/collect_profiles.py r04
-TAG=${TAG:-r04}
+# TAG=r05 bash tools/final_session.sh ; then on the build box: python tools/collect_profiles.py r05
+TAG=${TAG:-r05}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 if [ -z "$SKIP_TESTS" ]; then
@@ -13,6 +13,9 @@ python tools/bench_configs.py > gpurun_out/cfg.log 2>&1
 python tools/bench_chain.py > gpurun_out/chain.log 2>&1
 python tools/bench_montecarlo.py > gpurun_out/mc.log 2>&1
 python tools/bench_all_z.py > gpurun_out/allz.log 2>&1
+# round 5: the same landscape under the reference's only mode (parity stop at each size's waterfall), with and without slot refill
+STOP=1 python tools/bench_all_z.py > gpurun_out/allz_stop.log 2>&1
+STOP=1 OUT_SUFFIX=_norefill NRLDPC_NO_REFILL=1 python tools/bench_all_z.py > gpurun_out/allz_stop_norefill.log 2>&1
 if [ -z "$SKIP_HOST" ]; then python tools/bench_host_path.py > gpurun_out/hostpath.log 2>&1; fi
 # round 4: pruned layer counts (three routes), CRC-aided stop, BASELINE configs[4] as the bench leg at N = 1, host-path phase trace
 python tools/bench_nl.py default > gpurun_out/nl_default.log 2>&1
