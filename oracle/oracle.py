@@ -43,6 +43,17 @@ def lib():
         L.orc_rate_match.argtypes = [i32] * 9 + [P, P, i32, P]
         L.orc_crc.argtypes = [C.c_uint32, i32, P, i32]
         L.orc_crc.restype = C.c_uint32
+        # OpenMP's default team is every CPU the box SHOWS (256 on the MI355X boxes, of which the cgroup grants 16): a parallel
+        # region over a handful of codewords then costs 0.1-0.2 s in thread start-up and throttling -- test files run on their own
+        # took ten times as long as inside the whole suite, where an earlier test happened to set the count.  Bound it once, here.
+        n = os.cpu_count() or 1
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(q) // int(per)))
+        except (OSError, ValueError):
+            pass
+        L.orc_set_threads(n)
         _LIB = L
     return _LIB
 
