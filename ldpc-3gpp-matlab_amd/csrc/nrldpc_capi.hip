@@ -1163,6 +1163,37 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
         nrldpc_top_block(llr, hq_kind, (size_t)batch, 0, 1, s.Z, s.g.ncols, s.g.kb + 4, &best);
         nl = layers_of_block(s, best);
     }
+    // The reference's own call pattern -- one step() = the C code blocks of one transport block (NRLDPCDecoder.m:257-266), i.e. a
+    // call of one to a few codewords -- is bound by latency, not by bytes: three hipMemcpyAsync calls on pageable memory (each
+    // staged and synchronised inside the runtime) and the kernel launches were 0.09 ms of a 0.12 ms call.  Small calls therefore go
+    // ZERO-COPY: the caller's LLRs are narrowed / copied into a pinned buffer that the decoder kernel reads over PCIe in its
+    // prologue (hipHostMalloc'd memory is device-accessible at the same address), hard decisions (bit-packed by the pack kernel
+    // when asked) and iteration counts are written by the kernels straight into pinned memory, and the call is: one CPU copy in,
+    // one or two launches, one stream synchronisation, one CPU copy out.  NRLDPC_HOST_ZEROCOPY_KB: largest input (device format)
+    // that goes this way, default 2048; 0 = off (A/B).
+    static const size_t zc_max = (size_t)(getenv("NRLDPC_HOST_ZEROCOPY_KB") ? atol(getenv("NRLDPC_HOST_ZEROCOPY_KB")) : 2048) << 10;
+    if (!app_out && !h->timing && in_bytes <= zc_max) {
+        HIP_TRY(h->pin_in[0].reserve(in_bytes));
+        HIP_TRY(h->pin_out[0].reserve((size_t)batch * KO));
+        if (iters_out) HIP_TRY(h->pin_it[0].reserve((size_t)batch * 4));
+        if (!h->xs[0]) HIP_TRY(hipStreamCreateWithFlags(&h->xs[0], hipStreamNonBlocking));
+        if (f64) {
+            const double* d = static_cast<const double*>(llr);
+            float* o = reinterpret_cast<float*>(h->pin_in[0].p);
+            for (size_t i = 0; i < (size_t)batch * ncw; ++i) o[i] = (float)d[i];
+        } else {
+            memcpy(h->pin_in[0].p, llr, in_bytes);
+        }
+        uint8_t* d_out = reinterpret_cast<uint8_t*>(h->pin_out[0].p);
+        int rc = decode_launch(h, h->pin_in[0].p, batch, packed ? h->s_hard.p : d_out, iters_out ? reinterpret_cast<int32_t*>(h->pin_it[0].p) : nullptr,
+                               nullptr, h->xs[0], nl);
+        if (rc) { (void)hipStreamSynchronize(h->xs[0]); return rc; }
+        if (packed) HIP_TRY(nrldpc::launch_pack_bits(h->s_hard.p, d_out, batch, (int)K, h->xs[0]));
+        HIP_TRY(hipStreamSynchronize(h->xs[0]));
+        memcpy(hard, d_out, (size_t)batch * KO);
+        if (iters_out) memcpy(iters_out, h->pin_it[0].p, (size_t)batch * 4);
+        return NRLDPC_OK;
+    }
     const void* src = llr;
     if (f64) { // MATLAB doubles: narrow on the host (halves PCIe bytes)
         h->h_narrow.resize((size_t)batch * ncw);
