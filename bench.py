@@ -313,7 +313,27 @@ def e2e_host_path(nrldpc, info_host, llr_host_f16, rule, reps=7):
                      "value": n * K / ts[len(ts) // 2] / 1e9, "unit": "Gbit/s", "runs": reps,
                      "host_bytes_in": int(x.nbytes), "host_bytes_out": int(n * ((K + 7) // 8 if packed else K))}
     out["r89_active_layers"] = e2e_active_layers(nrldpc, reps)
+    out["host_dram_read"] = host_dram_read(llr_host_f16.astype(np.float64))
+    d = out["host_dram_read"]
+    out["f64_matlab_double"]["read_bound_ms"] = out["f64_matlab_double"]["host_bytes_in"] / (d["GB_per_s"] * 1e9) * 1e3
     return out
+
+
+def host_dram_read(x, threads=15):
+    """What THIS box's host memory gives the copy threads: the 856 MB double array of the f64 leg summed by `threads` threads
+    (numpy releases the GIL inside sum), best of 3.  The f64 leg cannot be faster than bytes / this rate -- the boxes the builder saw
+    ranged from 90 to 250 GB/s, which is the whole spread of that leg (4.0 - 10 ms)."""
+    from concurrent.futures import ThreadPoolExecutor
+    flat = x.reshape(-1)
+    cuts = [len(flat) * i // threads for i in range(threads + 1)]
+    best = None
+    with ThreadPoolExecutor(threads) as ex:
+        for _ in range(3):
+            t0 = time.perf_counter()
+            list(ex.map(lambda i: float(flat[cuts[i]:cuts[i + 1]].sum()), range(threads)))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    return {"bytes": int(flat.nbytes), "threads": threads, "seconds": best, "GB_per_s": flat.nbytes / best / 1e9}
 
 
 def e2e_active_layers(nrldpc, reps=7, n=4096):
