@@ -32,7 +32,7 @@ template <int BG, int ZC, int NL = BGT<BG>::ROWS> struct Z64P : Z64<BG, ZC, 1, N
     // cost a workgroup per CU -- without them the parity-stop build spills 130 registers at 80 VGPRs
     // flags: [NCW] "slot c's codeword has a violated check", "some slot goes on", "some slot took a new codeword"; then the slots of
     // the parity-stop builds: [NCW] codeword index, [NCW] iterations it has had (nrldpc_decode_z64p_kernel)
-    static constexpr int SLOT0 = (NCW + 2 + 3) / 4 * 4;
+    static constexpr int SLOT0 = (NCW + 3 + 3) / 4 * 4; // (+ one sticky word: "the batch counter has run out")
     static constexpr size_t XOFF = FLAGS + 4 * (size_t)((SLOT0 + 2 * NCW + 3) / 4 * 4);
     static constexpr size_t XBYTES = (size_t)(B::NLT - 4) * ZC;
     static constexpr int wgs_per_cu(size_t lds) {
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
     int* slot_it = slot_cw + G::NCW;
     if constexpr (ETP) {
         if (half == 0 && z == 0) { slot_cw[c] = present ? cw : a.batch; slot_it[c] = 0; }
+        if (tid == 0) flags[G::NCW + 2] = a.work ? 0 : 1; // sticky: no counter, or the counter has run past the batch -- nothing left to take
     }
 
     // hard decisions of this thread's columns of codeword `cwi` (the halves take alternate columns) + the iteration count
@@ -263,7 +264,10 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
             __syncthreads(); // the last group's writes
             if (present) write_out(where(), cw, a.max_iter);
         } else {
-            for (;;) {
+            // Refills are taken every (refill_mask + 1)-th iteration only: a refill stalls the whole workgroup for an atomic's round
+            // trip and an HBM load latency, and with NCW >= 16 some slot finishes in almost every iteration -- a finished slot then
+            // waits half an iteration on average, the workgroup stalls half as often (DecArgs::refill_mask: the launcher's policy)
+            for (int wit = 0;; ++wit) {
                 iteration();
                 // parity check of this half's rows, per slot: flags[c] = "the codeword in slot c has a violated check",
                 // flags[NCW] = "some slot goes on", flags[NCW + 1] = "some slot took a new codeword"
@@ -275,7 +279,9 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                 const int c = p.c;                      // (this shadows the prologue's copy on purpose: see `where`)
                 const int cwi = slot_cw[c];             // the slot's codeword and the iterations it has had, this one included
                 const int iti = slot_it[c] + 1;
-                const bool empty = cwi >= a.batch;      // the batch is exhausted: the slot's lanes decode nothing anybody reads
+                const bool empty = cwi >= a.batch;      // a free slot (waiting for its refill, or the batch has run out): its lanes decode nothing anybody reads
+                const bool exhausted = flags[G::NCW + 2] != 0;
+                const bool refill_now = (wit & a.refill_mask) == a.refill_mask;
                 uint32_t bad = 0;
                 bool stop = false; // wave-uniform: every lane's codeword is settled (violated, or out of the vote)
                 auto vote = [&]() {
@@ -313,18 +319,26 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                 // a finished codeword's result leaves now, by its own lanes ...
                 const bool fin = !empty && (flags[c] == 0 || iti >= a.max_iter);
                 if (fin) write_out(p, cwi, iti);
-                // ... and the slot's first lane of half 0 takes the next codeword of the batch (or none: the slot stays empty)
+                // ... and the first lane of half 0 of a FREE slot (just finished, or waiting since an earlier iteration) takes the next
+                // codeword of the batch on a refill iteration; otherwise the slot stays free and keeps the workgroup alive until then
+                const bool free_slot = fin || empty;
                 if (p.half == 0 && p.z == 0) {
-                    if (fin) {
-                        int nxt = a.batch;
-                        if (a.work) nxt = atomicAdd(a.work, 1);
-                        if (nxt >= a.batch) nxt = a.batch;
-                        slot_cw[c] = nxt;
-                        slot_it[c] = 0;
-                        if (nxt < a.batch) { flags[G::NCW] = 1; flags[G::NCW + 1] = 1; }
-                    } else if (!empty) {
+                    if (!free_slot) {
                         slot_it[c] = iti;
                         flags[G::NCW] = 1;
+                    } else {
+                        int nxt = a.batch;
+                        if (!exhausted) {
+                            if (refill_now) {
+                                nxt = atomicAdd(a.work, 1);
+                                if (nxt >= a.batch) { nxt = a.batch; flags[G::NCW + 2] = 1; }
+                                else { flags[G::NCW] = 1; flags[G::NCW + 1] = 1; }
+                            } else {
+                                flags[G::NCW] = 1; // its refill comes
+                            }
+                        }
+                        slot_cw[c] = nxt;
+                        slot_it[c] = 0;
                     }
                 }
                 __syncthreads();
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(2 * z64p_rw(BG, ZC) * 64, (z64p_wpe<BG, ZC, NL>()))
                 if (__builtin_amdgcn_readfirstlane(flags[G::NCW + 1]) != 0) {  // some slot starts a new codeword: its lanes load it
                     const Where q = where();
                     const int nw = slot_cw[q.c];
-                    const bool refill = fin && nw < a.batch;
+                    const bool refill = free_slot && nw < a.batch;
                     if (__any((int)refill)) {
                         load_core(q, refill, true, nw);
                         load_ext(q.z, refill, true, nw);
@@ -379,6 +393,10 @@ template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t la
     int grid = (a.batch + G::NCW - 1) / G::NCW;
     DecArgs b = a;
     static const bool no_refill = getenv("NRLDPC_NO_REFILL") != nullptr; // A/B: every workgroup decodes its own NCW codewords and leaves
+    // refills every iteration for the workgroups of few codewords, every second one from 16 slots on (measured: profiles/r05_refill_period.txt);
+    // NRLDPC_REFILL_MASK=0/1/3 forces every / every second / every fourth iteration (A/B)
+    static const int env_mask = getenv("NRLDPC_REFILL_MASK") ? atoi(getenv("NRLDPC_REFILL_MASK")) : -1;
+    b.refill_mask = env_mask >= 0 ? env_mask : (G::NCW >= 16 ? 1 : 0);
     // NRLDPC_REFILL_GRID=<n>: at most n workgroups per launch (tests: a small batch then goes through the refill path; read per call)
     int cap = resident[dev & 63];
     if (const char* e = getenv("NRLDPC_REFILL_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;

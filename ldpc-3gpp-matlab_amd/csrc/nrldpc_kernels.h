@@ -41,6 +41,8 @@ struct DecArgs {
     // one int of device memory per launch in flight (the handle's ring of them): the batch counter of the parity-stop kernels that
     // refill their codeword slots (nrldpc_decode_z64p.h); null = none (every workgroup decodes its own codewords and leaves)
     int32_t* work;
+    int32_t refill_mask; // those kernels take refills when (iteration & refill_mask) == refill_mask: 0 every iteration, 1 every second one
+    int32_t reserved_;
 };
 
 hipError_t launch_decode(int bg, const DecArgs& a, int threads, size_t lds_bytes, hipStream_t stream);
