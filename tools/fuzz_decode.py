@@ -2,7 +2,10 @@
 """Extended differential fuzz of the decoder kernels against the CPU oracle (the test-suite version runs 60
 cases; this runs N, default 600, biased towards the compile-time-Z sizes).  python tools/fuzz_decode.py [N] [seed]
 SMALL=1: biased towards the packed-geometry sizes (Z <= 80): pipelined builds (every row active, hard output) and the general
-kernel (pruned rows, soft output), ragged batches of up to 70 codewords."""
+kernel (pruned rows, soft output), ragged batches of up to 70 codewords.
+REFILL=1: the parity stop on the sizes whose workgroups hold several codewords (Z <= 192), batches of 40 ... 400 codewords decoded by 1 ... 4
+workgroups (NRLDPC_REFILL_GRID, read per call), so that every slot is refilled several times; any layer count, any SNR, any cap.  The refill period
+is a per-process setting: run once per NRLDPC_REFILL_MASK=0/1/3."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +19,15 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 BIG = [z for z in ALL_Z if z >= 52]
 SMALL = [z for z in ALL_Z if z <= 80] if os.environ.get("SMALL") else None
 for i in range(N):
+    if os.environ.get("REFILL"):
+        bg = int(rng.integers(1, 3)); Z = int(rng.choice([z for z in ALL_Z if z <= 192]))
+        os.environ["NRLDPC_REFILL_GRID"] = str(int(rng.integers(1, 5)))
+        T.run_case(pkg, orc, rng, bg, Z, int(rng.integers(40, 401)) if Z <= 64 else int(rng.integers(8, 60)), float(rng.uniform(-3.0, 6.0)), int(rng.integers(2, 21)),
+                   nl=0 if rng.random() < 0.5 else int(rng.integers(4, BG_DIMS[bg][0] + 1)), et=True,
+                   dt=[np.float16, np.float32][int(rng.integers(0, 2))], app=False)
+        if i % 50 == 49:
+            print(i + 1, "refill cases ok", flush=True)
+        continue
     if SMALL and rng.random() < 0.85:
         bg = int(rng.integers(1, 3)); Z = int(rng.choice(SMALL))
         T.run_case(pkg, orc, rng, bg, Z, int(rng.integers(1, 1 + max(8, min(70, 600 // Z)))), float(rng.uniform(-3.0, 5.0)), int(rng.integers(1, 13)),
