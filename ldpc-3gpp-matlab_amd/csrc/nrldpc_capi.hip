@@ -1174,7 +1174,7 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
     static const size_t zc_max = (size_t)(getenv("NRLDPC_HOST_ZEROCOPY_KB") ? atol(getenv("NRLDPC_HOST_ZEROCOPY_KB")) : 2048) << 10;
     if (!app_out && !h->timing && in_bytes <= zc_max) {
         HIP_TRY(h->pin_in[0].reserve(in_bytes));
-        HIP_TRY(h->pin_out[0].reserve((size_t)batch * KO));
+        HIP_TRY(h->pin_out[0].reserve((size_t)batch * K)); // one byte per bit from the kernel; bit-packed output is packed here, on the CPU
         if (iters_out) HIP_TRY(h->pin_it[0].reserve((size_t)batch * 4));
         if (!h->xs[0]) HIP_TRY(hipStreamCreateWithFlags(&h->xs[0], hipStreamNonBlocking));
         if (f64) {
@@ -1185,12 +1185,28 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             memcpy(h->pin_in[0].p, llr, in_bytes);
         }
         uint8_t* d_out = reinterpret_cast<uint8_t*>(h->pin_out[0].p);
-        int rc = decode_launch(h, h->pin_in[0].p, batch, packed ? h->s_hard.p : d_out, iters_out ? reinterpret_cast<int32_t*>(h->pin_it[0].p) : nullptr,
-                               nullptr, h->xs[0], nl);
+        int rc = decode_launch(h, h->pin_in[0].p, batch, d_out, iters_out ? reinterpret_cast<int32_t*>(h->pin_it[0].p) : nullptr, nullptr, h->xs[0], nl);
         if (rc) { (void)hipStreamSynchronize(h->xs[0]); return rc; }
-        if (packed) HIP_TRY(nrldpc::launch_pack_bits(h->s_hard.p, d_out, batch, (int)K, h->xs[0]));
         HIP_TRY(hipStreamSynchronize(h->xs[0]));
-        memcpy(hard, d_out, (size_t)batch * KO);
+        if (packed) { // a few kilobytes: packing them here saves the pack kernel's launch (one launch per call instead of two)
+            for (size_t b = 0; b < (size_t)batch; ++b) {
+                const uint8_t* src = d_out + b * K;
+                uint8_t* dst = hard + b * KO;
+                size_t k = 0;
+                for (; k + 8 <= K; k += 8) {
+                    uint64_t x;
+                    memcpy(&x, src + k, 8);
+                    dst[k >> 3] = (uint8_t)(((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+                }
+                if (k < K) {
+                    unsigned v = 0;
+                    for (size_t j = k; j < K; ++j) v |= (unsigned)(src[j] & 1u) << (j - k);
+                    dst[k >> 3] = (uint8_t)v;
+                }
+            }
+        } else {
+            memcpy(hard, d_out, (size_t)batch * K);
+        }
         if (iters_out) memcpy(iters_out, h->pin_it[0].p, (size_t)batch * 4);
         return NRLDPC_OK;
     }

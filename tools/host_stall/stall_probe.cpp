@@ -2,7 +2,7 @@
 // no Python, no torch, output arrays allocated and touched once.  Used to take apart the alternating 25-35 ms wait of
 // nrldpc_decode (byte-per-bit output) that round 4 left open.
 //   g++ -O2 -std=c++17 -I include tools/host_stall/stall_probe.cpp -L ldpc-3gpp-matlab_amd -lnrldpc_hip -o stall_probe
-//   NRLDPC_HOST_TRACE=1 ./stall_probe f16|f32|f64 packed(0|1) reps [batch] [bg] [Z] [n_layers] [zero_from_col]
+//   NRLDPC_HOST_TRACE=1 ./stall_probe f16|f32|f64 packed(0|1) reps [batch] [bg] [Z] [n_layers] [zero_from_col] [early_term]
 //   n_layers: 0 all rows, 4.., -1 = NRLDPC_LAYERS_AUTO; zero_from_col: base-graph columns from this one on hold LLR 0 (a rate-matched block)
 #include <chrono>
 #include <cmath>
@@ -47,11 +47,11 @@ int main(int argc, char** argv) {
     const char* dt = argv[1];
     const int packed = std::atoi(argv[2]), reps = std::atoi(argv[3]);
     const int batch = argc > 4 ? std::atoi(argv[4]) : 4096, bg = argc > 5 ? std::atoi(argv[5]) : 1, Z = argc > 6 ? std::atoi(argv[6]) : 384;
-    const int nl = argc > 7 ? std::atoi(argv[7]) : 0, zero_from = argc > 8 ? std::atoi(argv[8]) : 1 << 30;
+    const int nl = argc > 7 ? std::atoi(argv[7]) : 0, zero_from = argc > 8 ? std::atoi(argv[8]) : 1 << 30, et = argc > 9 ? std::atoi(argv[9]) : 0;
     nrldpc_cfg cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = sizeof cfg;
-    cfg.bg = bg; cfg.Z = Z; cfg.max_iter = 25; cfg.early_term = 0; cfg.n_layers = nl;
+    cfg.bg = bg; cfg.Z = Z; cfg.max_iter = 25; cfg.early_term = et; cfg.n_layers = nl;
     cfg.llr_dtype = !std::strcmp(dt, "f64") ? NRLDPC_LLR_F64 : !std::strcmp(dt, "f16") ? NRLDPC_LLR_F16 : NRLDPC_LLR_F32;
     nrldpc_handle h = nullptr;
     if (nrldpc_create(&cfg, &h) != NRLDPC_OK) { std::fprintf(stderr, "create: %s\n", nrldpc_last_error()); return 1; }
