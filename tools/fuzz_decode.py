@@ -18,7 +18,27 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 BIG = [z for z in ALL_Z if z >= 52]
 SMALL = [z for z in ALL_Z if z <= 80] if os.environ.get("SMALL") else None
+from conftest import awgn_llr, rule_kw
 for i in range(N):
+    if os.environ.get("AUTO"):  # NRLDPC_LAYERS_AUTO (ABI revision 5): a rate-matched batch (zero tail), the count read off the data, host and pipelined paths
+        bg = int(rng.integers(1, 3)); Z = int(rng.choice(ALL_Z)); rows, cols, kb = BG_DIMS[bg]
+        nl = int(rng.integers(4, rows + 1)); B = int(rng.integers(1, 9)) if Z > 64 else int(rng.integers(1, 200))
+        if rng.random() < 0.08: B = max(B, (9 << 20) // (cols * Z * 2) + 3)  # above 8 MB: the pipelined host path
+        dt = [np.float16, np.float32, np.float64][int(rng.integers(0, 3))]
+        et = bool(rng.integers(0, 2)); iters = int(rng.integers(1, 13))
+        info = rng.integers(0, 2, (B, kb * Z), dtype=np.uint8)
+        llr = awgn_llr(rng, orc.encode(bg, Z, info), float(rng.uniform(-2.0, 7.0)), dt, Z, E=(kb + nl - 2) * Z)
+        c = pkg.Codec(bg, Z, max_iter=iters, n_layers=-1, early_term=et, llr_dtype=dt)
+        h, it = c.decode(llr, want_iters=True)
+        used = c.last_layers()
+        c.close()
+        assert used == nl, (bg, Z, nl, used)
+        a_, b_ = pkg._capi.default_rule(bg, nl)
+        ref = orc.decode_nmsq(bg, Z, llr.astype(np.float32).astype(np.float64), iters, n_layers=nl, early_term=et, alpha=a_, beta=b_ * 8)
+        assert (h == ref[0]).all() and (it == ref[1]).all(), (bg, Z, nl, B, dt, et, iters)
+        if i % 50 == 49:
+            print(i + 1, "auto cases ok", flush=True)
+        continue
     if os.environ.get("REFILL"):
         bg = int(rng.integers(1, 3)); Z = int(rng.choice([z for z in ALL_Z if z <= 192]))
         os.environ["NRLDPC_REFILL_GRID"] = str(int(rng.integers(1, 5)))
