@@ -380,17 +380,29 @@ class CodecPool:
             pass
 
 
+class MultiCall:
+    """The argument arrays of one nrldpc_decode_multi_dev call, built once: what a C caller holds anyway.  call(stream) is the
+    library call and nothing else (marshalling 5 x 100 values through ctypes costs about as much as the call's host side)."""
+
+    def __init__(self, codecs, d_llr, batch, d_hard, d_iters=None):
+        n = self.n = len(codecs)
+        vp = C.c_void_p
+        self.codecs = list(codecs)  # keeps the handles alive
+        self.hs = (vp * n)(*[c._h for c in codecs])
+        self.llr = (vp * n)(*[int(x) for x in d_llr])
+        self.hard = (vp * n)(*[int(x) for x in d_hard])
+        self.its = (vp * n)(*[int(x) if x else None for x in d_iters]) if d_iters is not None else None
+        self.bt = (C.c_int32 * n)(*[int(b) for b in batch])
+        self.fn = load().nrldpc_decode_multi_dev
+
+    def __call__(self, stream=0):
+        check(self.fn(self.n, self.hs, self.llr, self.bt, self.hard, self.its, C.c_void_p(stream)))
+
+
 def decode_multi_dev(codecs, d_llr, batch, d_hard, d_iters=None, stream=0):
-    """One launch per base graph and LLR type for a mix of configurations (nrldpc_decode_multi_dev):
+    """One launch per base graph, LLR type and workgroup class for a mix of configurations (nrldpc_decode_multi_dev):
     codecs[i] decodes batch[i] codewords at device address d_llr[i] into d_hard[i] (and d_iters[i])."""
-    n = len(codecs)
-    vp = C.c_void_p
-    hs = (vp * n)(*[c._h for c in codecs])
-    llr = (vp * n)(*[int(x) for x in d_llr])
-    hard = (vp * n)(*[int(x) for x in d_hard])
-    its = (vp * n)(*[int(x) if x else None for x in d_iters]) if d_iters is not None else None
-    bt = (C.c_int32 * n)(*[int(b) for b in batch])
-    check(load().nrldpc_decode_multi_dev(n, hs, llr, bt, hard, its, C.c_void_p(stream)))
+    MultiCall(codecs, d_llr, batch, d_hard, d_iters)(stream)
 
 
 def rate_recover_dev(p, d_g_tilde, n_tb, d_harq, d_cw_llr, out_dtype=LLR_F32, stream=0):

@@ -387,8 +387,9 @@ struct nrldpc_codec {
     // side streams for the launches of one nrldpc_decode_multi_dev call: each launch is bound by its slowest
     // workgroups (25 iterations of a codeword that never converges), not by throughput, so the launches of the two
     // base graphs overlap almost perfectly (fork / join with events around the caller's stream)
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    static constexpr int kSide = 7;
+    hipStream_t side[kSide] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kSide] = {};
     // pipelined host path (large batches): two pinned slots, two streams, copy threads
     static constexpr int kSlots = 4; // chunks the host may run ahead of the device
     PinBuf pin_in[kSlots], pin_out[kSlots], pin_it[kSlots];
@@ -708,7 +709,7 @@ void nrldpc_destroy(nrldpc_handle h) {
     h->d_row_ptr.release(); h->d_col.release(); h->d_shift.release();
     h->s_llr.release(); h->s_q.release(); h->s_hard.release(); h->s_bits.release(); h->s_pk.release(); h->s_iters.release(); h->s_app.release();
     for (auto& m : h->multi) { m.pin.release(); m.dev.release(); if (m.done) (void)hipEventDestroy(m.done); }
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < nrldpc_codec::kSide; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
@@ -825,8 +826,26 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
     // never converge.
     static const long env_rows = getenv("NRLDPC_MULTI_Z64_MIN_ROWS") ? atol(getenv("NRLDPC_MULTI_Z64_MIN_ROWS")) : 512L * 384L;
     static const bool one_stream = getenv("NRLDPC_MULTI_ONE_STREAM") != nullptr; // A/B
-    struct Group { std::vector<nrldpc::DecArgs> args; std::vector<int32_t> start; size_t lds = 0; int grid = 0; };
-    Group g[2][2];
+    // The shared launches: one per (base graph, LLR type, workgroup class).  A launch has ONE workgroup size and ONE dynamic-LDS
+    // size, and the run-time-Z body keeps every wave of the workgroup to the end: launched together, a 256-thread configuration
+    // (27 KB of LDS, four workgroups per CU by its schedule) would run at the residency of a 512-thread one.  Classes: up to 256
+    // threads, up to 512, above.  NRLDPC_MULTI_CLASSES=0: one launch per (base graph, LLR type) as before (A/B).
+    static const bool env_classes = !(getenv("NRLDPC_MULTI_CLASSES") && atoi(getenv("NRLDPC_MULTI_CLASSES")) == 0);
+    constexpr int kClasses = 6;
+    static int edges[kClasses] = {256, 512, 768, 768, 768, 768}; // NRLDPC_MULTI_CLASS_EDGES=a,b,...: ascending thread counts (experiments)
+    static const bool edges_read = [] {
+        const char* e = getenv("NRLDPC_MULTI_CLASS_EDGES");
+        for (int i = 0; e && *e && i < kClasses - 1; ++i) {
+            edges[i] = atoi(e);
+            for (int j = i + 1; j < kClasses; ++j) edges[j] = 768;
+            e = strchr(e, ',');
+            if (e) ++e;
+        }
+        return true;
+    }();
+    (void)edges_read;
+    struct Group { std::vector<nrldpc::DecArgs> args; std::vector<int32_t> start; size_t lds = 0; int grid = 0, threads = 0; };
+    Group g[2][2][kClasses];
     std::vector<int> routed;
     // layer count of every configuration: its handle's, or (NRLDPC_LAYERS_AUTO) read off its codewords -- all pre-pass kernels
     // are queued first and the stream is synchronised ONCE for the lot
@@ -856,30 +875,35 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
         const nrldpc::Schedule& s = h->sched;
         // (a handle with the CRC-aided stop always gets a launch of its own: the shared kernel is built without it)
         if (h->cfg.early_term == 2 || ((long)batch[i] * s.Z >= env_rows && nrldpc::has_z64_kernel(s.g.bg, s.Z))) { routed.push_back(i); continue; }
-        Group& q = g[s.g.bg - 1][h->cfg.llr_dtype == NRLDPC_LLR_F16 ? 1 : 0];
+        int cls = kClasses - 1;
+        if (env_classes)
+            for (cls = 0; cls < kClasses - 1 && s.threads > edges[cls]; ++cls) {}
+        Group& q = g[s.g.bg - 1][h->cfg.llr_dtype == NRLDPC_LLR_F16 ? 1 : 0][cls];
         q.args.push_back(make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr, nls[i]));
         h->last_layers = nls[i];
         q.start.push_back(q.grid);
         q.grid += (batch[i] + s.ncw - 1) / s.ncw;
         q.lds = std::max(q.lds, s.lds_bytes);
+        q.threads = std::max(q.threads, s.threads);
     }
     std::vector<char> host;
-    size_t off[2][2][2];
+    size_t off[2][2][kClasses][2];
     int nlaunch = (int)routed.size();
     for (int b = 0; b < 2; ++b)
-        for (int d = 0; d < 2; ++d) {
-            Group& q = g[b][d];
-            if (q.args.empty()) continue;
-            ++nlaunch;
-            q.start.push_back(q.grid);
-            host.resize((host.size() + 15) & ~(size_t)15);
-            off[b][d][0] = host.size();
-            host.insert(host.end(), reinterpret_cast<const char*>(q.args.data()),
-                        reinterpret_cast<const char*>(q.args.data() + q.args.size()));
-            off[b][d][1] = host.size();
-            host.insert(host.end(), reinterpret_cast<const char*>(q.start.data()),
-                        reinterpret_cast<const char*>(q.start.data() + q.start.size()));
-        }
+        for (int d = 0; d < 2; ++d)
+            for (int c = 0; c < kClasses; ++c) {
+                Group& q = g[b][d][c];
+                if (q.args.empty()) continue;
+                ++nlaunch;
+                q.start.push_back(q.grid);
+                host.resize((host.size() + 15) & ~(size_t)15);
+                off[b][d][c][0] = host.size();
+                host.insert(host.end(), reinterpret_cast<const char*>(q.args.data()),
+                            reinterpret_cast<const char*>(q.args.data() + q.args.size()));
+                off[b][d][c][1] = host.size();
+                host.insert(host.end(), reinterpret_cast<const char*>(q.start.data()),
+                            reinterpret_cast<const char*>(q.start.data() + q.start.size()));
+            }
     if (nlaunch == 0) return NRLDPC_OK;
     // table slot: reused only after the launches that read it have completed (calls on different streams may overlap)
     nrldpc_codec::MultiSlot& m = own->multi[own->multi_next];
@@ -893,27 +917,31 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
         HIP_TRY(hipMemcpyAsync(m.dev.p, m.pin.p, host.size(), hipMemcpyHostToDevice, st));
     }
     const bool fan = nlaunch > 1 && !one_stream;
+    static const int env_side = getenv("NRLDPC_MULTI_STREAMS") ? atoi(getenv("NRLDPC_MULTI_STREAMS")) : 5;
+    const int nside = std::max(1, std::min({env_side, (int)nrldpc_codec::kSide, nlaunch - 1}));
     if (fan) { // fork: the side streams start after the table copy (and everything the caller queued before it)
         if (!own->ev_fork) HIP_TRY(hipEventCreateWithFlags(&own->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(own->ev_fork, st));
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < nside; ++i) {
             if (!own->side[i]) HIP_TRY(hipStreamCreateWithFlags(&own->side[i], hipStreamNonBlocking));
             if (!own->ev_join[i]) HIP_TRY(hipEventCreateWithFlags(&own->ev_join[i], hipEventDisableTiming));
             HIP_TRY(hipStreamWaitEvent(own->side[i], own->ev_fork, 0));
         }
     }
     int rc = NRLDPC_OK, k = 0;
-    auto next_stream = [&]() -> hipStream_t { const int q = k++ & 3; return (!fan || q == 0) ? st : own->side[q - 1]; };
+    auto next_stream = [&]() -> hipStream_t { const int q = k++ % (nside + 1); return (!fan || q == 0) ? st : own->side[q - 1]; };
     // shared launches first (the longest: their tail of never-converging small codewords), then the buckets' own
-    for (int b = 0; b < 2 && rc == NRLDPC_OK; ++b)
-        for (int d = 0; d < 2 && rc == NRLDPC_OK; ++d) {
-            const Group& q = g[b][d];
-            if (q.args.empty()) continue;
-            hipError_t e = nrldpc::launch_decode_multi(
-                b + 1, d ? NRLDPC_K_F16 : NRLDPC_K_F32, reinterpret_cast<const nrldpc::DecArgs*>(m.dev.p + off[b][d][0]),
-                reinterpret_cast<const int32_t*>(m.dev.p + off[b][d][1]), (int)q.args.size(), q.grid, q.lds, next_stream());
-            if (e != hipSuccess) rc = hipfail(e, "multi-configuration decode launch");
-        }
+    // (the largest class first: its workgroups are the longest)
+    for (int c = kClasses - 1; c >= 0 && rc == NRLDPC_OK; --c)
+        for (int b = 0; b < 2 && rc == NRLDPC_OK; ++b)
+            for (int d = 0; d < 2 && rc == NRLDPC_OK; ++d) {
+                const Group& q = g[b][d][c];
+                if (q.args.empty()) continue;
+                hipError_t e = nrldpc::launch_decode_multi_wg(
+                    b + 1, d ? NRLDPC_K_F16 : NRLDPC_K_F32, reinterpret_cast<const nrldpc::DecArgs*>(m.dev.p + off[b][d][c][0]),
+                    reinterpret_cast<const int32_t*>(m.dev.p + off[b][d][c][1]), (int)q.args.size(), q.grid, q.threads, q.lds, next_stream());
+                if (e != hipSuccess) rc = hipfail(e, "multi-configuration decode launch");
+            }
     for (size_t r = 0; r < routed.size() && rc == NRLDPC_OK; ++r) {
         const int i = routed[r];
         nrldpc_codec* h = hs[i];
@@ -924,7 +952,7 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
         if (e != hipSuccess) rc = hipfail(e, "decode kernel launch");
     }
     if (fan)
-        for (int i = 0; i < 3; ++i) { // join: the caller's stream continues after every side launch
+        for (int i = 0; i < nside; ++i) { // join: the caller's stream continues after every side launch
             (void)hipEventRecord(own->ev_join[i], own->side[i]);
             (void)hipStreamWaitEvent(st, own->ev_join[i], 0);
         }

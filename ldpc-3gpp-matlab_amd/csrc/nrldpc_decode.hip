@@ -23,6 +23,7 @@
 
 #include "nrldpc_device.h"
 #include "nrldpc_dispatch_lists.h"
+#include "nrldpc_hostpath.h"
 
 namespace nrldpc {
 
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(768, BG == 2 ? NRLDPC_GEN_WPE_BG2 : NRLDPC_GEN_WPE_
     decode_body<BG, DT>(a, a.rot, (int)blockIdx.x - st[lo]);
 }
 
-template <int BG, int DT> static hipError_t launch_multi_t(const DecArgs* d_tab, const int32_t* d_start, int nb, int grid,
+template <int BG, int DT> static hipError_t launch_multi_t(const DecArgs* d_tab, const int32_t* d_start, int nb, int grid, int threads,
                                                            size_t lds, hipStream_t s) {
     auto k = nrldpc_decode_multi_kernel<BG, DT>;
     static bool attr_set[64] = {};
@@ -313,18 +314,25 @@ template <int BG, int DT> static hipError_t launch_multi_t(const DecArgs* d_tab,
         if (e != hipSuccess) return e;
         attr_set[dev & 63] = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(BG == 1 ? NRLDPC_GEN_THREADS_BG1 : NRLDPC_GEN_THREADS_BG2), lds, s, d_tab, d_start, nb);
+    if (threads <= 0 || threads > 768 || threads % 64) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, d_tab, d_start, nb);
     return hipGetLastError();
+}
+
+hipError_t launch_decode_multi_wg(int bg, int llr_kind, const DecArgs* d_tab, const int32_t* d_start, int nb, int grid, int threads,
+                                  size_t lds_bytes, hipStream_t stream) {
+    const bool f16 = llr_kind == NRLDPC_K_F16;
+    if (bg == 1)
+        return f16 ? launch_multi_t<1, NRLDPC_K_F16>(d_tab, d_start, nb, grid, threads, lds_bytes, stream)
+                   : launch_multi_t<1, NRLDPC_K_F32>(d_tab, d_start, nb, grid, threads, lds_bytes, stream);
+    return f16 ? launch_multi_t<2, NRLDPC_K_F16>(d_tab, d_start, nb, grid, threads, lds_bytes, stream)
+               : launch_multi_t<2, NRLDPC_K_F32>(d_tab, d_start, nb, grid, threads, lds_bytes, stream);
 }
 
 hipError_t launch_decode_multi(int bg, int llr_kind, const DecArgs* d_tab, const int32_t* d_start, int nb, int grid,
                                size_t lds_bytes, hipStream_t stream) {
-    const bool f16 = llr_kind == NRLDPC_K_F16;
-    if (bg == 1)
-        return f16 ? launch_multi_t<1, NRLDPC_K_F16>(d_tab, d_start, nb, grid, lds_bytes, stream)
-                   : launch_multi_t<1, NRLDPC_K_F32>(d_tab, d_start, nb, grid, lds_bytes, stream);
-    return f16 ? launch_multi_t<2, NRLDPC_K_F16>(d_tab, d_start, nb, grid, lds_bytes, stream)
-               : launch_multi_t<2, NRLDPC_K_F32>(d_tab, d_start, nb, grid, lds_bytes, stream);
+    return launch_decode_multi_wg(bg, llr_kind, d_tab, d_start, nb, grid, bg == 1 ? NRLDPC_GEN_THREADS_BG1 : NRLDPC_GEN_THREADS_BG2,
+                                  lds_bytes, stream);
 }
 
 template <int BG, int DT, bool CRC = false> static hipError_t launch_t(const DecArgs& a, int grid, int threads, size_t lds, hipStream_t s) {

@@ -19,5 +19,12 @@ hipError_t launch_expand_i8_rows(const int8_t* d_q, void* d_out_f16, size_t n_ro
 // One wave per (block, codeword) pair, top block first; a wave whose block is not above *d_best leaves at once, so the pass reads
 // the all-zero column blocks once and almost nothing else.  HBM-bound.
 hipError_t launch_top_block(const void* d_llr, int llr_kind, int batch, int Z, int nblocks, int first, int* d_best, hipStream_t stream);
+struct DecArgs;
+// the shared launch of nrldpc_decode_multi_dev (nrldpc_decode.hip) with the workgroup size given: the configurations of one launch
+// share its workgroup size and its dynamic LDS, so the caller groups them by what their schedules ask for (nrldpc_sched.h) and a
+// 256-thread configuration is not held to the residency of a 512-thread one.  threads: a multiple of 64, at least every
+// configuration's Schedule::threads, at most 768
+hipError_t launch_decode_multi_wg(int bg, int llr_kind, const DecArgs* d_tab, const int32_t* d_start, int nb, int grid, int threads,
+                                  size_t lds_bytes, hipStream_t stream);
 } // namespace nrldpc
 #endif

@@ -78,26 +78,39 @@ def mixed(B=8192, iters=25):
         t = (time.perf_counter() - t0) * 1e3
         best = t if best is None else min(best, t)
     per_bucket = best
-    # the same batch through nrldpc_decode_multi_dev: one launch per base graph
+    # the same batch through ONE nrldpc_decode_multi_dev call.  The argument arrays are built once, as a C caller holds them:
+    # marshalling them through ctypes inside the timed region cost 0.06-0.09 ms of the 0.61 ms this line showed through round 5's
+    # first sessions (wall_ms_with_python_marshalling keeps that form)
     ref = [w[2].clone() for w in work]
     s0 = torch.cuda.current_stream().cuda_stream
+    call = pkg.MultiCall([w[0] for w in work], [w[1].data_ptr() for w in work], [w[3] for w in work],
+                         [w[2].data_ptr() for w in work], None)
     best = None
-    for _ in range(6):
+    for _ in range(8):
         for w in work:
             w[2].zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        call(s0)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) * 1e3
+        best = t if best is None else min(best, t)
+    assert all(bool((w[2] == r).all()) for w, r in zip(work, ref)), "multi launch differs from per-bucket launches"
+    best_py = None
+    for _ in range(4):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pkg.decode_multi_dev([w[0] for w in work], [w[1].data_ptr() for w in work], [w[3] for w in work],
                              [w[2].data_ptr() for w in work], None, s0)
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) * 1e3
-        best = t if best is None else min(best, t)
+        best_py = t if best_py is None else min(best_py, t)
     assert all(bool((w[2] == r).all()) for w, r in zip(work, ref)), "multi launch differs from per-bucket launches"
     bits = sum(n * K for _, _, _, n, K in work)
     for w in work:
         w[0].close()
-    rec = {"config": "cfg4 mixed BG1/BG2, Z in {2..384}, batch 8192, nrldpc_decode_multi_dev (one launch per base graph)",
-           "buckets": len(work), "wall_ms": best, "info_Gbit_s": bits / best / 1e6, "info_bits": bits,
+    rec = {"config": "cfg4 mixed BG1/BG2, Z in {2..384}, batch 8192, nrldpc_decode_multi_dev (one call)",
+           "buckets": len(work), "wall_ms": best, "wall_ms_with_python_marshalling": best_py, "info_Gbit_s": bits / best / 1e6, "info_bits": bits,
            "wall_ms_one_launch_per_bucket_8_streams": per_bucket, "info_Gbit_s_one_launch_per_bucket": bits / per_bucket / 1e6}
     print(rec, flush=True)
     return rec

@@ -19,11 +19,11 @@ for (bg, Z), n in sorted(buckets.items()):
     iters = torch.zeros(n, device="cuda", dtype=torch.int32)
     work.append((codec, llr, hard, n, kb * Z, iters, bg, Z))
 s0 = torch.cuda.current_stream().cuda_stream
-args = ([w[0] for w in work], [w[1].data_ptr() for w in work], [w[3] for w in work], [w[2].data_ptr() for w in work], [w[5].data_ptr() for w in work], s0)
-for rep in range(6):
+call = pkg.MultiCall([w[0] for w in work], [w[1].data_ptr() for w in work], [w[3] for w in work], [w[2].data_ptr() for w in work], [w[5].data_ptr() for w in work])
+for rep in range(8):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pkg.decode_multi_dev(*args)
+    call(s0)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
