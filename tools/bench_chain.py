@@ -114,7 +114,7 @@ def main():
     res += run("BG1 A=25344 C=4 64QAM R~1/2, 1024 transport blocks", 1024, True, BG=1, A=25344, G=50688 + 12, Q_m=6)
     res += run("cfg1 BG2 A=100 R=1/3 QPSK, 65536 transport blocks", 65536, False, BG=2, A=100, G=300, Q_m=2)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "bench_chain.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "bench_chain%s.json" % os.environ.get("OUT_SUFFIX", "")), "w") as f:
         json.dump(res, f, indent=1)
 
 
