@@ -5,7 +5,10 @@ SMALL=1: biased towards the packed-geometry sizes (Z <= 80): pipelined builds (e
 kernel (pruned rows, soft output), ragged batches of up to 70 codewords.
 REFILL=1: the parity stop on the sizes whose workgroups hold several codewords (Z <= 192), batches of 40 ... 400 codewords decoded by 1 ... 4
 workgroups (NRLDPC_REFILL_GRID, read per call), so that every slot is refilled several times; any layer count, any SNR, any cap.  The refill period
-is a per-process setting: run once per NRLDPC_REFILL_MASK=0/1/3."""
+is a per-process setting: run once per NRLDPC_REFILL_MASK=0/1/3.
+MULTI=1: nrldpc_decode_multi_dev -- each case one call over 2 ... 14 configurations drawn at random ((BG, Z), layer count given / AUTO / all rows,
+fp16 or fp32 LLRs, 1 ... 90 codewords each, a bucket now and then large enough for a launch of its own), every configuration against the oracle:
+the shared launches' workgroup classes and prefix tables, the routing, the per-handle layer counts."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,6 +23,37 @@ BIG = [z for z in ALL_Z if z >= 52]
 SMALL = [z for z in ALL_Z if z <= 80] if os.environ.get("SMALL") else None
 from conftest import awgn_llr, rule_kw
 for i in range(N):
+    if os.environ.get("MULTI"):
+        import torch
+        et = bool(rng.random() < 0.8); iters = int(rng.integers(1, 11)); snr = float(rng.uniform(-1.0, 6.0))
+        work = []
+        for _ in range(int(rng.integers(2, 15))):
+            bg = int(rng.integers(1, 3)); Z = int(rng.choice(ALL_Z)); rows, cols, kb = BG_DIMS[bg]
+            mode = int(rng.integers(0, 3))  # 0 all rows, 1 the count given, 2 AUTO
+            nl = rows if mode == 0 else int(rng.integers(4, rows + 1))
+            B = int(rng.integers(1, 91)) if Z <= 96 else int(rng.integers(1, 13))
+            if rng.random() < 0.04: B = 512 * 384 // Z + 1  # its own launch (NRLDPC_MULTI_Z64_MIN_ROWS)
+            dt = [np.float16, np.float32][int(rng.integers(0, 2))]
+            info = rng.integers(0, 2, (B, kb * Z), dtype=np.uint8)
+            llr = awgn_llr(rng, orc.encode(bg, Z, info), snr, dt, Z, E=(kb + nl - 2) * Z if mode else None)
+            c = pkg.Codec(bg, Z, max_iter=iters, n_layers=(0, nl, -1)[mode], early_term=et, llr_dtype=dt)
+            d = torch.from_numpy(llr).cuda()
+            work.append((c, d, torch.full((B, kb * Z), 7, dtype=torch.uint8, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda"), bg, Z, nl, llr))
+        seen = set(); uniq = []
+        for w in work:  # (a handle under AUTO may appear once per call; handles here are all distinct anyway)
+            uniq.append(w)
+        pkg.MultiCall([w[0] for w in uniq], [w[1].data_ptr() for w in uniq], [w[1].shape[0] for w in uniq], [w[2].data_ptr() for w in uniq],
+                      [w[3].data_ptr() for w in uniq])(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for c, d, hard, its, bg, Z, nl, llr in uniq:
+            a_, b_ = pkg._capi.default_rule(bg, nl)
+            ref = orc.decode_nmsq(bg, Z, llr.astype(np.float32).astype(np.float64), iters, n_layers=nl, early_term=et, alpha=a_, beta=b_ * 8)
+            assert c.last_layers() == nl, (bg, Z, nl, c.last_layers())
+            assert (hard.cpu().numpy() == ref[0]).all() and (its.cpu().numpy() == ref[1]).all(), (bg, Z, nl, llr.shape, llr.dtype, et, iters)
+            c.close()
+        if i % 20 == 19:
+            print(i + 1, "multi cases ok", flush=True)
+        continue
     if os.environ.get("AUTO"):  # NRLDPC_LAYERS_AUTO (ABI revision 5): a rate-matched batch (zero tail), the count read off the data, host and pipelined paths
         bg = int(rng.integers(1, 3)); Z = int(rng.choice(ALL_Z)); rows, cols, kb = BG_DIMS[bg]
         nl = int(rng.integers(4, rows + 1)); B = int(rng.integers(1, 9)) if Z > 64 else int(rng.integers(1, 200))
