@@ -98,7 +98,7 @@ def usable_cpus():
 def bler_match():
     """Second half of the metric ('BLER match vs MATLAB ref'; the decoder arithmetic of the reference is closed source, so
     this is a match to a restatement of its documented algorithm -- PARITY UNPINNED): the dB gap to
-    flooding sum-product at equal iteration caps at BLER 0.1 and 0.01, and -- recorded, not bounded -- to the reference's
+    flooding sum-product at equal iteration caps at BLER 0.1, 0.01 and 0.001, and -- recorded, not bounded -- to the reference's
     default of 50 sweeps (NRLDPCDecoder.m:41); measured by tests/test_bler_gap_gpu.py on identical noise, committed under
     profiles/."""
     for tag in PROFILE_TAGS:
@@ -114,7 +114,8 @@ def bler_match():
                        "bound_dB": head["bound_dB"],
                        "source": "profiles/%s_bler_gap.json (tests/test_bler_gap_gpu.py)" % tag}
                 for k in ("gap_dB_at_bler_0.01", "bound_dB_at_bler_0.01", "blocks_at_bler_0.01",
-                          "gap_dB_vs_50_sum_product_sweeps_at_bler_0.01"):
+                          "gap_dB_vs_50_sum_product_sweeps_at_bler_0.01",
+                          "gap_dB_at_bler_0.001", "bound_dB_at_bler_0.001", "blocks_at_bler_0.001"):  # 1e-3: plot_BLER_vs_SNR.m:38
                     if k in head:
                         out["headline_" + k] = head[k]
                 # round 4: the reference's own operating points (tests/test_bler_gap_gpu.py, same file)

@@ -27,6 +27,11 @@ CASES_1E2 = [
     ("cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25, [-1.35, -1.30, -1.25], [-1.65, -1.60, -1.55], 4096),
     ("cfg3 BG2 Z=384 R=1/3 25it", 2, 384, 3840, 11472, 22, 25, [-1.30, -1.20, -1.10], [-1.60, -1.50, -1.40], 4096),
 ]
+# BLER 1e-3 -- where the reference's sweep stops (target_BLER, plot_BLER_vs_SNR.m:38) -- at equal caps, on 16384 blocks:
+# name, bg, Z, K', E, layers, iteration cap, grid of the GPU decoder, grid of the sum-product oracle, blocks
+CASES_1E3 = [
+    ("cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25, [-1.30, -1.25, -1.20, -1.15], [-1.30, -1.25, -1.20], 16384),
+]
 # name, bg, Z, K', E, layers, grid of the GPU decoder, grid of the sum-product oracle, blocks
 CASES_50 = [
     ("cfg2 headline BG1 Z=384 R=1/3 50it", 1, 384, 8448, 25272, 46, [-1.50, -1.45, -1.40, -1.35, -1.30], [-1.70, -1.65, -1.60, -1.55], 4096),
@@ -71,6 +76,11 @@ def inputs_1e2(case, encode, first=None):
     return Inputs(name + " 1e-2", bg, Z, Kp, E, nblk, encode, True, first)
 
 
+def inputs_1e3(case, encode, first=None):
+    name, bg, Z, Kp, E, nl, iters, snrs, snrs_bp, nblk = case
+    return Inputs(name + " 1e-3", bg, Z, Kp, E, nblk, encode, True, first)
+
+
 def inputs_50(case, encode, first=None):
     name, bg, Z, Kp, E, nl, snrs, snrs_bp, nblk = case
     return Inputs(name, bg, Z, Kp, E, nblk, encode, True, first)
@@ -90,6 +100,9 @@ def runs():
     for c in CASES_50:
         for snr in c[7]:
             out.append(("50/%s/%g" % (c[0], snr), inputs_50, c, c[1], c[2], c[5], 50, snr))
+    for c in CASES_1E3:
+        for snr in c[8]:
+            out.append(("1e3/%s/%g" % (c[0], snr), inputs_1e3, c, c[1], c[2], c[5], c[6], snr))
     return out
 
 

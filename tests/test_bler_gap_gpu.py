@@ -31,6 +31,7 @@ pytestmark = pytest.mark.gpu
 BOUND_DB = 0.10  # stated bound at equal iteration caps, every BASELINE configuration
 TARGET = 0.1
 BOUND_DB_1E2 = 0.10  # stated bound at BLER 1e-2, equal iteration caps (headline, cfg3 R = 1/3)
+BOUND_DB_1E3 = 0.10  # stated bound at BLER 1e-3 (the reference sweep's stopping point, plot_BLER_vs_SNR.m:38), equal caps, headline
 
 
 def _threads():
@@ -45,7 +46,7 @@ def _threads():
     return n
 
 import bler_cases as BC  # noqa: E402  (the cases, their seeded inputs and the committed sum-product outcomes)
-from bler_cases import CASES, CASES_1E2, CASES_50  # noqa: E402
+from bler_cases import CASES, CASES_1E2, CASES_1E3, CASES_50  # noqa: E402
 
 REF = BC.Ref(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bler_ref.npz")
              if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bler_ref.npz")) else None)
@@ -148,6 +149,41 @@ def test_db_gap_at_bler_1e2(pkg, orc, case):
     print(extra)
     assert x_gpu is not None and x_bp is not None, "grid does not bracket BLER 1e-2: %s %s" % (b_gpu, b_bp)
     assert x_gpu - x_bp <= BOUND_DB_1E2, extra
+
+
+@pytest.mark.parametrize("case", CASES_1E3, ids=[c[0] for c in CASES_1E3])
+def test_db_gap_at_bler_1e3(pkg, orc, case):
+    """Where the reference's sweep stops -- target_BLER = 1e-3 (plot_BLER_vs_SNR.m:38) -- on 16384 blocks with identical payloads and
+    noise: Es/N0 at which the GPU decoder and flooding sum-product (committed outcomes, tests/golden/bler_ref.npz) cross BLER 1e-3 at
+    equal iteration caps.  Bounded by BOUND_DB_1E3."""
+    name, bg, Z, Kp, E, nl, iters, snrs, snrs_bp, nblk = case
+    codec = pkg.Codec(bg, Z, max_iter=iters, n_layers=nl, early_term=True, llr_dtype=np.float32)
+    inp = BC.inputs_1e3(case, orc.encode)
+    info = inp.info
+    b_gpu, b_bp = [], []
+    for snr in snrs:
+        llr = inp.llr_at(snr)
+        hg = codec.decode(llr.astype(np.float32))
+        b_gpu.append(float((hg[:, :Kp] != info[:, :Kp]).any(1).mean()))
+        if snr in snrs_bp:
+            b_bp.append(float(sum_product(orc, "1e3/%s/%g" % (name, snr), inp, llr, bg, Z, nl, iters)[0].mean()))
+    codec.close()
+    x_gpu, x_bp = crossing(snrs, b_gpu, nblk, 1e-3), crossing(snrs_bp, b_bp, nblk, 1e-3)
+    extra = {"blocks_at_bler_0.001": nblk, "EsN0_dB_at_bler_0.001_grid_gpu": snrs, "EsN0_dB_at_bler_0.001_grid_sum_product": snrs_bp,
+             "bler_gpu_at_0.001": b_gpu, "bler_sum_product_at_0.001": b_bp, "EsN0_at_bler_0.001_gpu": x_gpu, "EsN0_at_bler_0.001_sum_product": x_bp,
+             "gap_dB_at_bler_0.001": None if x_gpu is None or x_bp is None else x_gpu - x_bp, "bound_dB_at_bler_0.001": BOUND_DB_1E3}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        p = os.path.join(out, "bler_gap.json")
+        allr = json.load(open(p)) if os.path.exists(p) else {}
+        allr.setdefault(name, {"case": name}).update(extra)
+        json.dump(allr, open(p, "w"), indent=1)
+    except OSError:
+        pass
+    print(extra)
+    assert x_gpu is not None and x_bp is not None, "grids do not bracket BLER 1e-3: %s %s" % (b_gpu, b_bp)
+    assert x_gpu - x_bp <= BOUND_DB_1E3, extra
 
 
 # ---- round 4 (VERDICT r3 item 4): the reference's own operating points ----------------------------------------------------
