@@ -26,11 +26,13 @@ CASES = [
 CASES_1E2 = [
     ("cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25, [-1.35, -1.30, -1.25], [-1.65, -1.60, -1.55], 4096),
     ("cfg3 BG2 Z=384 R=1/3 25it", 2, 384, 3840, 11472, 22, 25, [-1.30, -1.20, -1.10], [-1.60, -1.50, -1.40], 4096),
+    ("cfg5 BG1 Z=384 R=8/9 25it", 1, 384, 8448, 9478, 5, 25, [6.1, 6.2, 6.3, 6.4], [6.0, 6.1, 6.2, 6.3], 4096),
 ]
 # BLER 1e-3 -- where the reference's sweep stops (target_BLER, plot_BLER_vs_SNR.m:38) -- at equal caps, on 16384 blocks:
 # name, bg, Z, K', E, layers, iteration cap, grid of the GPU decoder, grid of the sum-product oracle, blocks
 CASES_1E3 = [
     ("cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25, [-1.30, -1.25, -1.20, -1.15], [-1.30, -1.25, -1.20], 16384),
+    ("cfg3 BG2 Z=384 R=1/3 25it", 2, 384, 3840, 11472, 22, 25, [-1.25, -1.20, -1.15, -1.10], [-1.15, -1.10, -1.05, -1.00], 16384),
 ]
 # name, bg, Z, K', E, layers, grid of the GPU decoder, grid of the sum-product oracle, blocks
 CASES_50 = [
