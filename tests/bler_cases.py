@@ -33,6 +33,7 @@ CASES_1E2 = [
 CASES_1E3 = [
     ("cfg2 headline BG1 Z=384 R=1/3 25it", 1, 384, 8448, 25272, 46, 25, [-1.30, -1.25, -1.20, -1.15], [-1.30, -1.25, -1.20], 16384),
     ("cfg3 BG2 Z=384 R=1/3 25it", 2, 384, 3840, 11472, 22, 25, [-1.25, -1.20, -1.15, -1.10], [-1.15, -1.10, -1.05, -1.00], 16384),
+    ("cfg1 BG2 A=100 R=1/3 QPSK 10it", 2, 20, 116, 300, 12, 10, [1.4, 1.6, 1.8, 2.0], [2.0, 2.2, 2.4, 2.6], 65536),
 ]
 # name, bg, Z, K', E, layers, grid of the GPU decoder, grid of the sum-product oracle, blocks
 CASES_50 = [
