@@ -65,19 +65,24 @@ template <int NB> __device__ __forceinline__ void rail_llr(float y, float inv_n0
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int bit = (c >> (NB - 1 - k)) & 1u;
-            sm[k][bit] += expf(met[c] - mx[k][bit]);
+            sm[k][bit] += __builtin_amdgcn_exp2f((met[c] - mx[k][bit]) * 1.4426950408889634f); // e^x = 2^(x log2 e): v_exp_f32
         }
 #pragma unroll
-    for (int k = 0; k < NB; ++k) llr[k] = (mx[k][0] + logf(sm[k][0])) - (mx[k][1] + logf(sm[k][1]));
+    for (int k = 0; k < NB; ++k) // (sums lie in [1, 2^NB]: v_log_f32 needs no denormal care)
+        llr[k] = (mx[k][0] - mx[k][1]) + 0.6931471805599453f * (__builtin_amdgcn_logf(sm[k][0]) - __builtin_amdgcn_logf(sm[k][1]));
 }
 
 // LLRs of one symbol from its bits and the two uniform words of its noise sample
 template <int QM> __device__ __forceinline__ void symbol_llr(const ChanArgs& a, const uint8_t* g, uint32_t w1, uint32_t w2, float* o) {
     // Box-Muller on 24-bit uniforms in (0,1): exact in f32
     const float u1 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = ((float)(w2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float rad = sqrtf(-2.0f * logf(u1)) * a.sigma; // sigma = sqrt(N0/2) per rail
-    float sn, cs;
-    sincosf(6.283185307179586f * u2, &sn, &cs);
+    // The hardware's own transcendentals: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, so sin(2 pi u2) is one
+    // instruction on u2 itself -- no range reduction (the library sincosf carries a Payne-Hanek path for arguments it never gets
+    // here); v_log_f32 is log2, v_sqrt_f32 is within 1 ulp.  The kernel issues VALU instructions, not bytes (438 per thread before,
+    // most of them here and in Philox): it is bound by that, not by HBM.  Results move by ~1e-6 relative; the test's tolerance on an
+    // LLR is 5e-4 (tests/test_chain_gpu.py).
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * a.sigma; // -2 ln u1 = -2 ln2 log2 u1; sigma = sqrt(N0/2) per rail
+    const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
     const float ni = rad * cs, nq = rad * sn;
     if constexpr (QM == 1) { // comm.PSKModulator order 2, phase offset pi/4 (NRModulator.m:73): LLR = 4 Re(rx e^{-j pi/4}) / N0
         const float tx = (g[0] & 1u) ? -1.0f : 1.0f;
