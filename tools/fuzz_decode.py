@@ -39,9 +39,7 @@ for i in range(N):
             c = pkg.Codec(bg, Z, max_iter=iters, n_layers=(0, nl, -1)[mode], early_term=et, llr_dtype=dt)
             d = torch.from_numpy(llr).cuda()
             work.append((c, d, torch.full((B, kb * Z), 7, dtype=torch.uint8, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda"), bg, Z, nl, llr))
-        seen = set(); uniq = []
-        for w in work:  # (a handle under AUTO may appear once per call; handles here are all distinct anyway)
-            uniq.append(w)
+        uniq = work  # (a handle under AUTO may appear once per call: every configuration here has a handle of its own)
         pkg.MultiCall([w[0] for w in uniq], [w[1].data_ptr() for w in uniq], [w[1].shape[0] for w in uniq], [w[2].data_ptr() for w in uniq],
                       [w[3].data_ptr() for w in uniq])(torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
