@@ -16,10 +16,16 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <utility>
 
 #include "nrldpc_kernels.h"
 
 namespace nrldpc {
+
+template <class F, int... I> __device__ __forceinline__ void rm_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void rm_static_for(F&& f) { rm_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <typename T> __device__ __forceinline__ T to_out(float v);
 template <> __device__ __forceinline__ float to_out<float>(float v) { return v; }
@@ -203,37 +209,52 @@ __global__ __launch_bounds__(256) void nrldpc_rate_match_kernel(const TxRmArgs a
     const uint8_t* cw = a.cw + (size_t)blk * (2 * a.Z + a.N) + 2 * a.Z;
     const int nj = rows - j0 < 4 ? rows - j0 : 4; // j of this thread that exist
     uint32_t run[QM]; // byte t of run[i] = e(i*rows + j0 + t)
+    // No repetition (E <= P: every code block of a launch whose rate is above the mother code's -- the usual case): k < P always,
+    // and the index arithmetic is adds and compares.  With repetition k wraps around P: a division and a modulo per run and per
+    // gathered byte, ~35 VALU instructions each -- as one code path for both (the first version) the kernel issued 233 VALU
+    // instructions per thread for its 8 output bytes and ran at the rate it could issue them, not at the rate of its bytes.
+    const bool rep = E > P; // uniform over the workgroup
 #pragma unroll
     for (int i = 0; i < QM; ++i) {
         const int k = i * rows + j0;
-        int q = (k < P ? k : k % P) + nfk0; // repetition (E > P) wraps around the buffer
+        int q, kend; // q: position among the buffer's non-filler bits; kend: first k of the next repetition
+        if (rep) { const int d = k / P; q = k - d * P + nfk0; kend = P * (d + 1); }
+        else { q = k + nfk0; kend = P; }
         if (q >= P) q -= P;
         // four consecutive e indices are four consecutive bytes when the run stays below P in k (no repetition wrap) and
         // in q (no buffer wrap) and on one side of the filler gap
-        if (nj == 4 && k + 3 < P * (k / P + 1) && q + 3 < P && (q >= lo_f || q + 3 < lo_f)) {
+        if (nj == 4 && k + 3 < kend && q + 3 < P && (q >= lo_f || q + 3 < lo_f)) {
             run[i] = *reinterpret_cast<const u32_unaligned*>(cw + (q < lo_f ? q : q + F)) & 0x01010101u;
         } else {
             uint32_t w = 0;
             for (int t = 0; t < nj; ++t) {
                 const int kk = k + t;
-                int qq = (kk < P ? kk : kk % P) + nfk0;
+                int qq = (rep ? kk % P : kk) + nfk0;
                 if (qq >= P) qq -= P;
                 w |= (uint32_t)(cw[qq < lo_f ? qq : qq + F] & 1u) << (8 * t);
             }
             run[i] = w;
         }
     }
-    // interleave: output byte t*QM + i = byte t of run[i]
+    // interleave: output byte t*QM + i = byte t of run[i].  v_perm_b32 picks each byte of its result from the eight bytes of two
+    // registers (selector byte 0..3: the second source's byte, 4..7: the first's), so an output dword is one instruction where its
+    // four bytes come from two runs (Q_m <= 2) and three otherwise -- two pairs, then their low halves -- instead of twelve shifts,
+    // masks and ors.
     uint32_t out[QM];
-#pragma unroll
-    for (int o = 0; o < QM; ++o) out[o] = 0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < QM; ++i) {
-            const int ob = t * QM + i;
-            out[ob >> 2] |= ((run[i] >> (8 * t)) & 0xffu) << (8 * (ob & 3));
+    rm_static_for<QM>([&](auto oc) {
+        constexpr int o = decltype(oc)::value;
+        constexpr int t0 = (4 * o) / QM, i0 = (4 * o) % QM, t1 = (4 * o + 1) / QM, i1 = (4 * o + 1) % QM;
+        constexpr int t2 = (4 * o + 2) / QM, i2 = (4 * o + 2) % QM, t3 = (4 * o + 3) / QM, i3 = (4 * o + 3) % QM;
+        if constexpr (QM == 1) {
+            out[o] = run[0];
+        } else if constexpr (QM == 2) { // bytes (run0.t0, run1.t1, run0.t2, run1.t3)
+            out[o] = __builtin_amdgcn_perm(run[1], run[0], (uint32_t)(t0 | ((4 + t1) << 8) | (t2 << 16) | ((4 + t3) << 24)));
+        } else {
+            const uint32_t p01 = __builtin_amdgcn_perm(run[i1], run[i0], (uint32_t)(t0 | ((4 + t1) << 8) | 0x0c0c0000u));
+            const uint32_t p23 = __builtin_amdgcn_perm(run[i3], run[i2], (uint32_t)(t2 | ((4 + t3) << 8) | 0x0c0c0000u));
+            out[o] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
         }
+    });
     uint8_t* g = a.g + (size_t)tb * a.G + a.off[r] + (size_t)j0 * QM;
     if (nj == 4 && (reinterpret_cast<uintptr_t>(g) & 3) == 0) {
 #pragma unroll
