@@ -207,6 +207,25 @@ def simulate_point_device(chains, Q_m, EsN0, rv_id_sequence, batch, seed, first_
     return np.concatenate(out) if out else np.zeros(0, bool)
 
 
+def _count_outcomes(outcomes, found_start, errors, blocks, BLER, target_block_errors):
+    """The per-block bookkeeping of plot_BLER_vs_SNR.m:139-155 over one batch of outcomes (True = block decoded), in order:
+    before the curve has had its first success a failure ends the point with BLER = 1 (:139-141); afterwards blocks and errors
+    are counted until the error target is met.  Returns (found_start, keep_going, errors, blocks, BLER).  Whole-array arithmetic:
+    as a Python loop over millions of outcomes this was a fifth of a device sweep's wall time; tests/test_harness_golden.py holds
+    the loop and compares."""
+    ok = np.asarray(outcomes, dtype=bool)
+    if ok.size == 0:
+        return found_start, True, errors, blocks, BLER
+    if not found_start and not ok[0]:
+        return found_start, False, errors, blocks, 1.0
+    bad = np.cumsum(~ok) + errors
+    hit = np.nonzero(bad >= target_block_errors)[0]
+    n = int(hit[0]) + 1 if hit.size else ok.size          # blocks of this batch that are counted
+    errors = int(bad[n - 1])
+    blocks += n
+    return True, True, errors, blocks, errors / blocks
+
+
 def _num2str(x):
     """MATLAB num2str for the values used in the result file name (4 significant decimals, %g-like)."""
     if float(x) == int(x):
@@ -290,16 +309,8 @@ def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0
                                     first_block += batch
                                 else:
                                     outcomes = simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng)
-                                for good in outcomes:
-                                    if not found_start and not good:                                     # :139-141
-                                        keep_going, BLER = False, 1.0
-                                        break
-                                    found_start = True                                                   # :143
-                                    errors += int(not good)                                              # :146-148
-                                    blocks += 1                                                          # :152
-                                    BLER = errors / blocks                                               # :155
-                                    if errors >= target_block_errors:
-                                        break
+                                found_start, keep_going, errors, blocks, BLER = _count_outcomes(
+                                    outcomes, found_start, errors, blocks, BLER, target_block_errors)
                             if BLER < 1:                                                                 # :164-166
                                 fid.write("%f\t%e\n" % (EsN0, BLER))
                                 fid.flush()

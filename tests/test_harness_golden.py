@@ -17,3 +17,40 @@ def test_fixture_is_what_the_oracle_backed_harness_gives(pkg, orc):
             for ln in txt.splitlines():
                 e, b = ln.split("\t")
                 assert len(e.split(".")[1]) == 6 and "e" in b and 0.0 < float(b) < 1.0
+
+
+def _count_outcomes_loop(outcomes, found_start, errors, blocks, BLER, target_block_errors):
+    """plot_BLER_vs_SNR.m:139-155 block by block, as the reference writes it."""
+    keep_going = True
+    for good in outcomes:
+        if not found_start and not good:                                     # :139-141
+            keep_going, BLER = False, 1.0
+            break
+        found_start = True                                                   # :143
+        errors += int(not good)                                              # :146-148
+        blocks += 1                                                          # :152
+        BLER = errors / blocks                                               # :155
+        if errors >= target_block_errors:
+            break
+    return found_start, keep_going, errors, blocks, BLER
+
+
+def test_outcome_bookkeeping_is_the_reference_loop(pkg):
+    """harness._count_outcomes (whole-array arithmetic) against the per-block loop of plot_BLER_vs_SNR.m:139-155: random batches at
+    several error rates, chained the way the sweep chains them (state carried from batch to batch until the error target is met)."""
+    import importlib
+
+    import numpy as np
+    H = importlib.import_module("ldpc-3gpp-matlab_amd.harness")
+    rng = np.random.default_rng(5)
+    for trial in range(400):
+        p_bad = float(rng.choice([0.0, 0.001, 0.02, 0.3, 0.9, 1.0]))
+        target = int(rng.integers(1, 40))
+        a = b = (bool(rng.integers(0, 2)), True, 0, 0, 1.0)  # (found_start, keep_going, errors, blocks, BLER)
+        for _ in range(int(rng.integers(1, 6))):
+            if not a[1] or a[2] >= target:
+                break
+            ok = rng.random(int(rng.integers(1, 300))) >= p_bad
+            a = _count_outcomes_loop(list(ok), a[0], a[2], a[3], a[4], target)
+            b = H._count_outcomes(ok, b[0], b[2], b[3], b[4], target)
+            assert a == b, (trial, a, b)
