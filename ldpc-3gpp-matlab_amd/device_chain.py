@@ -10,6 +10,27 @@ from ._capi import LLR_F16, LLR_F32, Codec, NRLDPCError, crc_check_harq_dev, rat
 from .nrldpc import NRLDPC
 
 
+class _Derived:
+    """What a chain step needs of the parameter object's Dependent properties (NRLDPC.m:297-543), computed once per setting of the
+    settable ones: the mirror re-derives every Dependent property on every access, as the reference does, and a step reads a dozen
+    of them -- 1 ms of Python per step, a fifth of a small code's Monte-Carlo sweep."""
+    __slots__ = ("t", "C", "Z_c", "N", "K", "B", "N_cb", "A", "G", "BG", "act", "flags")
+
+    def __init__(self, p):
+        self.t = tb_params(p)
+        self.C, self.Z_c, self.N, self.K, self.B, self.N_cb, self.A, self.G, self.BG = p.C, p.Z_c, p.N, p.K, p.B, p.N_cb, p.A, p.G, p.BG
+        self.act = p.active_layers()
+        self.flags = list(p.CBGTI_flags)
+
+
+def _derived(chain):
+    p = chain.p
+    key = (p.BG, p.A, p.I_LBRM, p.TBS_LBRM, p.rv_id, p.G, p.Q_m, p.N_L, tuple(p.CBGTI))  # every settable property (NRLDPC.m:28-84)
+    if getattr(chain, "_dkey", None) != key:
+        chain._dval, chain._dkey = _Derived(p), key
+    return chain._dval
+
+
 class DeviceDecodeChain:
     """Batched NRLDPCDecoder.step on device tensors.  `params` is an NRLDPC parameter object (or any
     NRLDPCDecoder).  The DiscreteState of the reference (NRLDPCDecoder.m:64-95) lives in HBM, one row per transport
@@ -65,11 +86,11 @@ class DeviceDecodeChain:
             return self._step(g_tilde.contiguous())
 
     def _step(self, g_tilde):
-        torch, p = self.torch, self.p
-        n_tb, C_ = g_tilde.shape[0], p.C
-        t = tb_params(p)
+        torch, d = self.torch, _derived(self)
+        n_tb, C_ = g_tilde.shape[0], d.C
+        t = d.t
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        ncwz = 2 * p.Z_c + p.N
+        ncwz = 2 * d.Z_c + d.N
         if self.cb_pass is not None and self.cb_pass.shape[0] != n_tb:
             # see NRLDPCDecoder.step_batch: only HARQ state that is really pending makes a new batch size an error
             # (the check synchronises, but only on this rare path); without it a new batch size starts a new set
@@ -79,27 +100,27 @@ class DeviceDecodeChain:
             self.cb_pass = self.b_hat = self.harq = None
         if self.cb_pass is None:
             self.cb_pass = torch.zeros((n_tb, C_), dtype=torch.int32, device=self.dev)
-            self.b_hat = torch.zeros((n_tb, p.B), dtype=torch.uint8, device=self.dev)
+            self.b_hat = torch.zeros((n_tb, d.B), dtype=torch.uint8, device=self.dev)
             if self.I_HARQ:
-                self.harq = torch.zeros((n_tb, C_, p.N_cb), dtype=torch.float32, device=self.dev)
+                self.harq = torch.zeros((n_tb, C_, d.N_cb), dtype=torch.float32, device=self.dev)
         tdt = torch.float16 if self.llr_dtype == np.float16 else torch.float32
         cw_llr = torch.empty((n_tb * C_, ncwz), dtype=tdt, device=self.dev)
         rate_recover_dev(t, g_tilde.data_ptr(), n_tb, self.harq.data_ptr() if self.I_HARQ else None,
                          cw_llr.data_ptr(), LLR_F16 if tdt == torch.float16 else LLR_F32, stream)
-        rows = 46 if p.BG == 1 else 42
+        rows = 46 if d.BG == 1 else 42
         n_layers = rows
         if self.prune:
-            act = p.active_layers()
+            act = d.act
             self._layers_seen = max(self._layers_seen, act) if self.I_HARQ else act
             n_layers = self._layers_seen
         codec = self._codec_for(n_layers)
-        c_hat = torch.empty((n_tb * C_, p.K), dtype=torch.uint8, device=self.dev)
+        c_hat = torch.empty((n_tb * C_, d.K), dtype=torch.uint8, device=self.dev)
         iters = torch.empty(n_tb * C_, dtype=torch.int32, device=self.dev)
         codec.decode_dev(cw_llr.data_ptr(), n_tb * C_, c_hat.data_ptr(), iters.data_ptr(), None, stream)
         ok = torch.empty(n_tb, dtype=torch.int32, device=self.dev)
         crc_check_harq_dev(t, c_hat.data_ptr(), n_tb, self.b_hat.data_ptr(), ok.data_ptr(), self.cb_pass.data_ptr(),
-                           p.CBGTI_flags, self.I_HARQ != 0, stream)
-        return self.b_hat[:, : p.A].clone(), ok != 0, iters.view(n_tb, C_)
+                           d.flags, self.I_HARQ != 0, stream)
+        return self.b_hat[:, : d.A].clone(), ok != 0, iters.view(n_tb, C_)
 
 
 class DeviceEncodeChain:
@@ -132,14 +153,14 @@ class DeviceEncodeChain:
             return self._step(a.contiguous())
 
     def _step(self, a):
-        torch, p = self.torch, self.p
+        torch, d = self.torch, _derived(self)
         n_tb = a.shape[0]
-        t = tb_params(p)
+        t = d.t
         s = torch.cuda.current_stream(self.dev).cuda_stream
-        c = torch.empty((n_tb * p.C, p.K), dtype=torch.uint8, device=self.dev)
+        c = torch.empty((n_tb * d.C, d.K), dtype=torch.uint8, device=self.dev)
         self._crc_attach(t, a.data_ptr(), n_tb, c.data_ptr(), s)
-        cw = torch.empty((n_tb * p.C, 2 * p.Z_c + p.N), dtype=torch.uint8, device=self.dev)
-        self._codec.encode_dev(c.data_ptr(), n_tb * p.C, cw.data_ptr(), s)
-        g = torch.empty((n_tb, p.G), dtype=torch.uint8, device=self.dev)
+        cw = torch.empty((n_tb * d.C, 2 * d.Z_c + d.N), dtype=torch.uint8, device=self.dev)
+        self._codec.encode_dev(c.data_ptr(), n_tb * d.C, cw.data_ptr(), s)
+        g = torch.empty((n_tb, d.G), dtype=torch.uint8, device=self.dev)
         self._rate_match(t, cw.data_ptr(), n_tb, g.data_ptr(), s)
         return g
