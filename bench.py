@@ -154,7 +154,7 @@ def synth_llr(torch, codec, batch, seed, dev):
 CFG5_TOTAL, CFG5_LAYERS, CFG5_E, CFG5_ESN0 = 65536, 5, 9478, 7.5  # BASELINE.json configs[4]: BG1 Z=384 R=8/9, early termination
 
 
-def cfg5_strong_leg(torch, nrldpc, dist, args, world, rank, local_rank, dev, valu_insts_per_edge_iter):
+def cfg5_strong_leg(torch, nrldpc, comm, args, world, rank, local_rank, dev, valu_insts_per_edge_iter):
     """BASELINE.json configs[4] next to the headline when the job has more than one rank (or --cfg5): 65536 BG1 Z=384 R=8/9
     codewords (5 active rows, 27 of the 68 columns transmitted), early termination, STRONG-scaled -- the total is fixed and
     rank r decodes the contiguous slice [r*total/N, (r+1)*total/N) on its own GPU with its own handle, no data-path
@@ -189,8 +189,7 @@ def cfg5_strong_leg(torch, nrldpc, dist, args, world, rank, local_rank, dev, val
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
     steps = max(1, args.cfg5_steps)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -207,14 +206,7 @@ def cfg5_strong_leg(torch, nrldpc, dist, args, world, rank, local_rank, dev, val
     kms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
     mean_it = float(its.float().mean().item()) if n else 0.0
     bler = float((hard != info).any(dim=1).float().mean().item()) if n else 0.0
-    mine = [elapsed, kms, mean_it, bler, float(n)]
-    if dist is not None:
-        t = torch.tensor(mine, device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        allr = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allr, t)  # five numbers per rank: the leg's bookkeeping, not its data path
-        rows = [[float(v) for v in r.tolist()] for r in allr]
-    else:
-        rows = [mine]
+    rows = comm.gather([elapsed, kms, mean_it, bler, float(n)])  # five numbers per rank: the leg's bookkeeping, not its data path
     codec.close()
     if rank != 0:
         return None
@@ -375,56 +367,132 @@ def e2e_active_layers(nrldpc, reps=7, n=4096):
     return res
 
 
+class Comm:
+    """What the ranks of a job say to each other: a barrier, the maximum of a number, a few numbers per rank.  The DATA path has no
+    collective (codeword batches shard), so nothing here may be able to lose the run: the default process group is
+    always gloo (TCP on 127.0.0.1), and RCCL -- `--backend nccl`, the default -- is a second group that is PROBED (communicator
+    init + one all-reduce on the rank's GPU, in a thread with a time limit); only when every rank's probe succeeded do the
+    barrier and the reductions go over it.  Otherwise the line says so: comm.backend "gloo", comm.requested "nccl",
+    comm.fallback = the reason (RCCL has never run with more than one rank on this pool's boxes)."""
+
+    def __init__(self, torch, backend, world, rank, local_rank, use_gpu, probe_timeout=90.0):
+        self.torch, self.world, self.rank, self.dist, self.pg, self.dev = torch, world, rank, None, None, None
+        self.stuck = False  # a probe thread that never came back: leave through os._exit
+        self.info = {"backend": None, "world_size": world}
+        if world == 1:
+            return
+        import datetime
+        import torch.distributed as dist
+        self.dist = dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=max(600.0, 4 * probe_timeout)))
+        self.info = {"backend": "gloo", "world_size": dist.get_world_size(), "requested": backend, "fallback": None}
+        if backend != "nccl":
+            return
+        ok, why = self._probe_rccl(local_rank, use_gpu, probe_timeout)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # over gloo: every rank learns whether EVERY rank's probe succeeded
+        if int(flag.item()) == 1:
+            self.pg, self.dev = self._pg, torch.device("cuda", local_rank)
+            self.info.update({"backend": "nccl", "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())})
+        else:
+            self.info["fallback"] = why or "the RCCL probe failed on another rank"
+
+    def _probe_rccl(self, local_rank, use_gpu, limit):
+        import threading
+        torch, dist = self.torch, self.dist
+        if not use_gpu or not torch.cuda.is_available():
+            return False, "no HIP device in this process"
+        res = {}
+
+        def run():
+            try:
+                import datetime
+                torch.cuda.set_device(local_rank)  # the current device is per thread
+                pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=limit))
+                t = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(t, group=pg)
+                torch.cuda.synchronize()
+                if int(t.item()) != self.world:
+                    raise RuntimeError("all-reduce of ones gave %r for %d ranks" % (t.item(), self.world))
+                res["pg"] = pg
+            except BaseException as e:  # noqa: BLE001 -- whatever RCCL raises, the bench goes on over gloo
+                res["err"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(limit + 15.0)
+        if th.is_alive():
+            self.stuck = True
+            return False, "the RCCL probe did not return within %.0f s" % (limit + 15.0)
+        if "pg" in res:
+            self._pg = res["pg"]
+            return True, None
+        return False, res.get("err", "unknown RCCL failure")
+
+    def barrier(self):
+        if self.dist is None:
+            return
+        if self.pg is not None:
+            self.dist.barrier(group=self.pg, device_ids=[self.dev.index])
+        else:
+            self.dist.barrier()
+
+    def gather(self, values):
+        """values: a few floats of this rank -> [[...] per rank] on every rank (bookkeeping, never the data path)."""
+        if self.dist is None:
+            return [[float(v) for v in values]]
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.dev if self.pg is not None else "cpu")
+        allr = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(allr, t, group=self.pg)
+        return [[float(v) for v in r.tolist()] for r in allr]
+
+    def max(self, x):
+        return max(r[0] for r in self.gather([x]))
+
+    def close(self):
+        if self.dist is None:
+            return
+        self.barrier()
+        if self.stuck:  # a thread is still inside RCCL: a normal interpreter exit would wait for it
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+        self.dist.destroy_process_group()
+
+
 def dry_run(args, torch):
-    """The multi-rank protocol of main() with the GPU work replaced by a sleep: exercised by the CPU test suite under
-    gloo (tests/test_dist_cpu.py) so that the torch.distributed branch of this file is executed somewhere other than
-    the driver's 8-GPU run.  Prints a line marked dry_run; it carries no measurement."""
+    """The multi-rank protocol of main() with the GPU work replaced by a sleep: exercised by the CPU test suite
+    (tests/test_dist_cpu.py) so that the torch.distributed branch of this file -- Comm, with `--backend nccl` its probe and the
+    fall back to gloo -- is executed somewhere other than the driver's 8-GPU run.  Prints a line marked dry_run; no measurement."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.backend == "nccl" else args.backend)
-        assert dist.get_world_size() == args.gpus
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    comm = Comm(torch, args.backend, world, rank, int(os.environ.get("LOCAL_RANK", "0")), use_gpu=False)
+    assert comm.info["world_size"] == args.gpus
     for _ in range(args.warmup):
         time.sleep(0.001)
-    barrier()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (rank + 1))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # the collectives of the per-GPU bookkeeping and of the cfg5_strong leg: all_gather of a few numbers per rank
+    comm.barrier()
+    elapsed = comm.max(time.perf_counter() - t0)
+    # the per-GPU bookkeeping of the cfg5_strong leg: a few numbers per rank
     leg = None
-    if dist is not None:
+    if world > 1:
         lo, hi = args.cfg5_total * rank // world, args.cfg5_total * (rank + 1) // world
-        barrier()
+        comm.barrier()
         t0 = time.perf_counter()
         time.sleep(0.001 * (rank + 1))
-        barrier()
-        t = torch.tensor([time.perf_counter() - t0, float(hi - lo)], dtype=torch.float64)
-        allr = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allr, t)
+        comm.barrier()
+        rows = comm.gather([time.perf_counter() - t0, float(hi - lo)])
         leg = {"dry_run": True, "scaling": "strong", "n_gpus": world,
-               "per_gpu": [{"codewords": int(r[1].item()), "seconds": float(r[0].item())} for r in allr]}
+               "per_gpu": [{"codewords": int(r[1]), "seconds": r[0]} for r in rows]}
     if rank == 0:
         print(json.dumps({"metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
                           "dry_run": True, "value": None, "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak",
-                          "comm": {"backend": dist.get_backend() if dist is not None else None, "world_size": world},
-                          "cfg5_strong": leg}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+                          "comm": comm.info, "cfg5_strong": leg}), flush=True)
+    comm.close()
 
 
 def check_or_start_ranks(args):
@@ -453,6 +521,155 @@ def check_or_start_ranks(args):
     raise SystemExit(subprocess.call(cmd))
 
 
+def build_line(nrldpc, args, n_gpus, batch, elapsed, kms, kms_all, rule, bler, early, cfg5, comm_info):
+    """The JSON line of rank 0 (or of the one process of --in-process): value from the wall clock of the timed loop, the
+    roofline object from the event-pair kernel times of the same launches and the committed rocprofv3 summary of this build."""
+    kernel_ms = float(np.mean(kms))
+    kid = nrldpc.load().nrldpc_kernel_id().decode()
+    bid = nrldpc.load().nrldpc_build_id().decode()
+    tag, pmc, tr, mix = _profile(kid)
+    value = n_gpus * batch * args.steps * K / elapsed / 1e9
+    traffic = tr.get("hbm_bytes_per_launch")
+    scale = batch / float(BATCH)  # the committed profile is of the default batch
+    if traffic is not None:
+        traffic = traffic * scale
+
+    def c(name):
+        v = pmc.get(name, {}).get("mean_per_launch")
+        return None if v is None else v * scale
+    compulsory = batch * (N_CW * 2 + K)
+    alg_gbs = batch * ALG_BYTES_PER_CW / (kernel_ms * 1e-3) / 1e9
+    roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave64 VALU instructions/s",
+            "frac": None, "traffic": traffic, "kernel": pmc.get("_kernel"), "kernel_ms": kernel_ms,
+            "kernel_ms_median": float(np.median(kms)), "kernel_ms_min": float(np.min(kms)),
+            # the same kernel's average under rocprofv3 --kernel-trace (first launch left out), from the committed profile
+            # of this build: tracing adds a few per cent; kernel_ms above is what every fraction of this line divides by
+            "kernel_ms_rocprofv3_avg": (pmc.get("_kernel_trace", {}).get("avg_ns_without_first_launch") or 0.0) * 1e-6 * (batch / float(BATCH)) or None}
+    if c("SQ_INSTS_VALU"):
+        insts = c("SQ_INSTS_VALU")
+        rate = insts / (kernel_ms * 1e-3)
+        wc = c("SQ_WAVE_CYCLES")
+        cyc = c("GRBM_GUI_ACTIVE") / 8.0 if c("GRBM_GUI_ACTIVE") else None  # the counter is summed over the 8 XCDs
+        roof.update({
+            "achieved": rate, "frac": rate / VALU_PEAK_WAVE_INSTS, "insts_per_launch": insts,
+            "valu_insts_per_edge_iteration": insts / (batch * ITERS * NNZ * Z / 64.0),
+            "wave_cycle_split": None if not wc else {
+                "issuing": c("SQ_ACTIVE_INST_ANY") / wc, "issue_stalled": c("SQ_WAIT_INST_ANY") / wc,
+                "parked_at_waitcnt_or_barrier": c("SQ_WAIT_ANY") / wc},
+            "lds": None if not (c("SQ_LDS_IDX_ACTIVE") and cyc) else {
+                "busy_frac": c("SQ_LDS_IDX_ACTIVE") / (256 * cyc), "bank_conflict_cycles": c("SQ_LDS_BANK_CONFLICT"),
+                "note": "SQ_LDS_IDX_ACTIVE / (256 CUs x busy cycles): the LDS array is not the bound either"},
+            "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU op (MI355X_MICROARCH.md); instruction counts per "
+                    "launch are data-independent without early termination; half of this kernel's opcodes issue at 4 cycles "
+                    "on gfx950 (profiles/r03_ubench_valu_rates.txt), which cycle_weighted accounts for"})
+    if mix and mix.get("valu_ns_per_iteration_all_waves_of_a_row"):
+        # static: disassembly of the loaded kernels x measured per-opcode issue intervals (tools/isa_mix.py): the time the
+        # launch needs if the VALU pipes never idle = VALU-ns of one iteration of one codeword (ns per row-wave set x Z/64
+        # waves), x iterations x codewords, spread over the chip's 1024 SIMDs -- independent of how many codewords a CU holds
+        valu_ms = mix["valu_ns_per_iteration_all_waves_of_a_row"] * (Z / 64.0) * ITERS * batch / 1024.0 * 1e-6
+        roof["cycle_weighted"] = {"valu_bound_ms_per_launch": valu_ms, "frac": valu_ms / kernel_ms,
+                                  "valu_ns_per_iteration_all_waves_of_a_row": mix["valu_ns_per_iteration_all_waves_of_a_row"],
+                                  "source": "profiles/%s_headline_isa_mix.json" % tag}
+    if roof.get("insts_per_launch"):  # every rank decodes the same number of codewords for the same 25 iterations
+        roof["per_gpu"] = [{"rank": r, "kernel_ms": ms, "frac": roof["insts_per_launch"] / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS}
+                           for r, ms in enumerate(kms_all)]
+    else:
+        roof["per_gpu"] = [{"rank": r, "kernel_ms": ms, "frac": None} for r, ms in enumerate(kms_all)]
+    roof["profile"] = {"tag": tag, "nrldpc_kernel_id": kid, "nrldpc_build_id": bid,
+                       "matches_loaded_library": tag is not None,
+                       "source": None if tag is None else "profiles/%s_bench_pmc_summary.json, profiles/%s_bench_kernel_stats.csv "
+                                 "(rocprofv3 --kernel-trace --stats / --pmc, separate passes, of this command)" % (tag, tag)}
+    roof["context"] = {
+        "hbm_streaming_model": {
+            "bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_codeword": ALG_BYTES_PER_CW, "storage_bytes_per_message": S_BYTES,
+            "note": "SURVEY 8(d): bytes a decoder that streams a-posteriori values and messages through HBM every layer "
+                    "would move, at this kernel's storage width (int8); above 1 because a codeword stays in LDS/VGPRs for "
+                    "all %d iterations -- not a fraction of anything this kernel is bound by" % ITERS},
+        "hbm_measured": None if not traffic else {
+            "bytes_per_launch": traffic, "achieved": traffic / (kernel_ms * 1e-3) / 1e9, "unit": "GB/s",
+            "frac_of_peak": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "ratio_to_compulsory": traffic / compulsory, "compulsory_bytes_per_launch": compulsory,
+            "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes: every LLR read once, every "
+                    "hard bit written once, nothing else"}}
+    return {
+        "metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
+        "value": value, "unit": "Gbit/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "comm": comm_info,
+        "vs_baseline": None, "dtype": "i8 messages / integer-valued f32 a-posteriori (fp16 LLR input)",
+        "data": "synthetic",
+        "config": {"workload": "BG1 Z=384 (K=8448) R=1/3, 25 layered min-sum iterations, no early termination, "
+                               "batch=%d codewords per GPU, QPSK/AWGN Es/N0=%.1f dB" % (batch, ESN0_DB),
+                   "bg": BG, "Z": Z, "iterations": ITERS, "batch_per_gpu": batch, "n_layers": 46,
+                   "check_node_rule": {"alpha": rule[0], "beta_llr": rule[1], "source": "nrldpc_default_rule (cfg.alpha = 0)"},
+                   "sharding": "codeword batches per GPU, no collective"},
+        "roofline": roof,
+        "bler": bler,
+        "bler_match": bler_match(),
+        "early_term": early,
+        "cfg5_strong": cfg5,
+    }
+
+
+def valu_insts_per_edge_iteration(nrldpc, batch):
+    kid = nrldpc.load().nrldpc_kernel_id().decode()
+    _, pmc, _, _ = _profile(kid)
+    insts = (pmc.get("SQ_INSTS_VALU", {}).get("mean_per_launch") or 0.0) * (batch / float(BATCH))
+    return insts / (batch * ITERS * NNZ * Z / 64.0) if insts else None
+
+
+def in_process(args, torch, nrldpc):
+    """`--gpus N --in-process`: ONE process drives the N devices through nrldpc_pool_decode_dev (one handle, one host thread and
+    one private stream per device inside the library; plot_BLER_vs_SNR.m:23-27 runs "parallel instances" by hand) -- no
+    launcher, no process group, nothing that can fail to initialise.  Same workload per GPU, same timed region (K pool calls
+    bracketed by a synchronize of every device), same JSON line; per-GPU kernel times are the library's event pairs on each
+    shard's own launch stream (nrldpc_pool_last_kernel_ms).  --share-gpu: every shard on device 0 (the 1-GPU test aid)."""
+    n = args.gpus
+    ids = [0] * n if args.share_gpu else list(range(n))
+    if not args.share_gpu and torch.cuda.device_count() < n:
+        raise SystemExit("bench.py: --gpus %d --in-process but only %d HIP device(s) visible" % (n, torch.cuda.device_count()))
+    batch = args.batch
+    pool = nrldpc.CodecPool(BG, Z, ids, chunks_per_device=1, max_iter=ITERS, n_layers=0, early_term=False, llr_dtype=np.float16)
+    pool.set_timing(True)
+    infos, llrs, hards, rule = [], [], [], None
+    for i, d in enumerate(ids):
+        with torch.cuda.device(d):
+            dev = torch.device("cuda", d)
+            enc = nrldpc.Codec(BG, Z, max_iter=ITERS, n_layers=0, early_term=False, llr_dtype=np.float16, device_id=d)
+            rule = (enc.alpha, enc.beta)
+            info, llr = synth_llr(torch, enc, batch, 0xC0DE + 1 + i, dev)  # the seeds of ranks 0..N-1 of the launcher form
+            enc.close()
+            infos.append(info); llrs.append(llr); hards.append(torch.empty((batch, K), device=dev, dtype=torch.uint8))
+    d_llr, d_hard, counts = [x.data_ptr() for x in llrs], [x.data_ptr() for x in hards], [batch] * n
+
+    def sync_all():
+        for d in set(ids):
+            torch.cuda.synchronize(d)
+    for _ in range(args.warmup):
+        pool.decode_dev(d_llr, counts, d_hard)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pool.decode_dev(d_llr, counts, d_hard)  # returns when every shard's stream is idle
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    # event-pair kernel times: of the last timed call per shard, plus a second, untimed pass that reads them after every call
+    kms_rows = []
+    for _ in range(args.steps):
+        pool.decode_dev(d_llr, counts, d_hard)
+        kms_rows.append(pool.last_kernel_ms())
+    kms_all = [float(np.mean([r[i] for r in kms_rows])) for i in range(n)]
+    kms = [float(np.mean(r)) for r in kms_rows]  # per call: mean over the shards
+    bler = float(np.mean([float((h != i_).any(dim=1).float().mean().item()) for h, i_ in zip(hards, infos)]))
+    pool.close()
+    info = {"backend": None, "world_size": 1, "in_process": True, "shards": n, "devices": ids,
+            "note": "one process, nrldpc_pool_decode_dev: one host thread + stream per device inside the library, no process group; "
+                    "value = all shards' codewords / wall clock of the K pool calls; roofline.kernel_ms = event pairs on each shard's "
+                    "own stream (a second pass of K calls: reading them costs a host synchronisation per call)"}
+    out = build_line(nrldpc, args, n, batch, elapsed, kms, kms_all, rule, bler, None, None, info)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -465,15 +682,20 @@ def main():
     ap.add_argument("--cfg5", action="store_true", help="also run the cfg5_strong leg at N = 1 (it always runs with more than one rank)")
     ap.add_argument("--cfg5-total", type=int, default=CFG5_TOTAL, help="codewords in the WHOLE job of the cfg5_strong leg")
     ap.add_argument("--cfg5-steps", type=int, default=5, help="timed passes of the cfg5_strong leg")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-time (nccl = RCCL)")
-    ap.add_argument("--share-gpu", action="store_true", help="test aid for 1-GPU boxes: every rank uses device 0 (use "
-                    "with --backend gloo; RCCL refuses two ranks on one GPU)")
+    ap.add_argument("--backend", default="nccl", help="what carries the barrier / max-time of a multi-rank job: nccl (= RCCL; probed, "
+                    "with gloo as the fall back: the data path needs no collective) or gloo")
+    ap.add_argument("--in-process", action="store_true", help="drive the N GPUs from THIS process through nrldpc_pool_decode_dev: "
+                    "no launcher, no process group (a second route to the same line)")
+    ap.add_argument("--share-gpu", action="store_true", help="test aid for 1-GPU boxes: every rank / shard uses device 0")
     ap.add_argument("--dry-run", action="store_true", help="test aid: run the rank protocol (init, barrier, timed loop "
                     "bracket, max-over-ranks, one JSON line) without touching a GPU; the line says dry_run and is no result")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
-    check_or_start_ranks(args)
+    if args.in_process and os.environ.get("WORLD_SIZE") not in (None, "1"):
+        raise SystemExit("bench.py: --in-process is the one-process form; do not start it under a launcher (WORLD_SIZE=%s)" % os.environ["WORLD_SIZE"])
+    if not args.in_process:
+        check_or_start_ranks(args)
 
     import torch
     torch.set_num_threads(4)  # host-side tensor copies only; idle OpenMP workers would spend the container's CPU quota
@@ -481,32 +703,22 @@ def main():
         return dry_run(args, torch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and this framework has no CPU path")
+    nrldpc = importlib.import_module("ldpc-3gpp-matlab_amd")
+    if args.in_process:
+        return in_process(args, torch, nrldpc)
     if not args.share_gpu and torch.cuda.device_count() < args.gpus:
         raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible (one rank per GPU; --share-gpu is the "
                          "1-GPU test aid)" % (args.gpus, torch.cuda.device_count()))
-    nrldpc = importlib.import_module("ldpc-3gpp-matlab_amd")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))  # == args.gpus: check_or_start_ranks
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    comm = {"backend": None, "world_size": 1}
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-        # what the communication library itself says (nccl IS RCCL on ROCm); carries only the barrier and two small reductions
-        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None}
-        if comm["world_size"] != args.gpus:
-            raise SystemExit("bench.py: the process group holds %d ranks, --gpus says %d" % (comm["world_size"], args.gpus))
-    if args.share_gpu:
-        local_rank = 0
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the barrier and two small reductions: RCCL when it comes up on every rank, gloo otherwise (the line says which)
+    comm = Comm(torch, args.backend, world, rank, local_rank, use_gpu=True)
+    if comm.info["world_size"] != args.gpus:
+        raise SystemExit("bench.py: the process group holds %d ranks, --gpus says %d" % (comm.info["world_size"], args.gpus))
 
     batch = args.batch
     # alpha = 0: the C ABI's own check-node rule for this rate (nrldpc_default_rule), what a MEX gateway gets
@@ -523,8 +735,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -537,22 +748,13 @@ def main():
         step()
         e1.record(tstream)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = comm.max(time.perf_counter() - t0)
     kms = [e0.elapsed_time(e1) for e0, e1 in ev]
     kernel_ms = float(np.mean(kms))
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     bler = float((hard != info).any(dim=1).float().mean().item())
     # every rank's kernel time, for the per-GPU roofline fractions of the line (bookkeeping: one number per rank)
-    kms_all = [kernel_ms]
-    if dist is not None:
-        t = torch.tensor([kernel_ms], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        allr = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allr, t)
-        kms_all = [float(x.item()) for x in allr]
+    kms_all = [r[0] for r in comm.gather([kernel_ms])]
 
     # Extra leg, outside the timed region: the reference's own mode -- 'Parity check satisfied' (NRLDPCDecoder.m:120) --
     # on the same LLRs (rank 0 only; never `value`, whose workload is the fixed-25 configuration BASELINE.json names)
@@ -572,98 +774,13 @@ def main():
                  "max_iterations": ITERS, "EsN0_dB": ESN0_DB, "bler": float((hard_et != info).any(dim=1).float().mean().item()),
                  "note": "parity-check stop per codeword (the reference's only mode), same LLRs, median of 5 launches after 2"}
 
-    kid = nrldpc.load().nrldpc_kernel_id().decode()
-    bid = nrldpc.load().nrldpc_build_id().decode()
-    tag, pmc, tr, mix = _profile(kid)
-    insts_headline = (pmc.get("SQ_INSTS_VALU", {}).get("mean_per_launch") or 0.0) * (batch / float(BATCH))
-    insts_per_edge_iter = insts_headline / (batch * ITERS * NNZ * Z / 64.0) if insts_headline else None
     # BASELINE configs[4], strong-scaled over the ranks of the job (every rank takes part: it has a barrier of its own)
     cfg5 = None
     if world > 1 or args.cfg5:
-        cfg5 = cfg5_strong_leg(torch, nrldpc, dist, args, world, rank, local_rank, dev, insts_per_edge_iter)
+        cfg5 = cfg5_strong_leg(torch, nrldpc, comm, args, world, rank, local_rank, dev, valu_insts_per_edge_iteration(nrldpc, batch))
 
     if rank == 0:
-        value = world * batch * args.steps * K / elapsed / 1e9
-        traffic = tr.get("hbm_bytes_per_launch")
-        scale = batch / float(BATCH)  # the committed profile is of the default batch
-        if traffic is not None:
-            traffic = traffic * scale
-
-        def c(name):
-            v = pmc.get(name, {}).get("mean_per_launch")
-            return None if v is None else v * scale
-        compulsory = batch * (N_CW * 2 + K)
-        alg_gbs = batch * ALG_BYTES_PER_CW / (kernel_ms * 1e-3) / 1e9
-        roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave64 VALU instructions/s",
-                "frac": None, "traffic": traffic, "kernel": pmc.get("_kernel"), "kernel_ms": kernel_ms,
-                "kernel_ms_median": float(np.median(kms)), "kernel_ms_min": float(np.min(kms)),
-                # the same kernel's average under rocprofv3 --kernel-trace (first launch left out), from the committed profile
-                # of this build: tracing adds a few per cent; kernel_ms above is what every fraction of this line divides by
-                "kernel_ms_rocprofv3_avg": (pmc.get("_kernel_trace", {}).get("avg_ns_without_first_launch") or 0.0) * 1e-6 * (batch / float(BATCH)) or None}
-        if c("SQ_INSTS_VALU"):
-            insts = c("SQ_INSTS_VALU")
-            rate = insts / (kernel_ms * 1e-3)
-            wc = c("SQ_WAVE_CYCLES")
-            cyc = c("GRBM_GUI_ACTIVE") / 8.0 if c("GRBM_GUI_ACTIVE") else None  # the counter is summed over the 8 XCDs
-            roof.update({
-                "achieved": rate, "frac": rate / VALU_PEAK_WAVE_INSTS, "insts_per_launch": insts,
-                "valu_insts_per_edge_iteration": insts / (batch * ITERS * NNZ * Z / 64.0),
-                "wave_cycle_split": None if not wc else {
-                    "issuing": c("SQ_ACTIVE_INST_ANY") / wc, "issue_stalled": c("SQ_WAIT_INST_ANY") / wc,
-                    "parked_at_waitcnt_or_barrier": c("SQ_WAIT_ANY") / wc},
-                "lds": None if not (c("SQ_LDS_IDX_ACTIVE") and cyc) else {
-                    "busy_frac": c("SQ_LDS_IDX_ACTIVE") / (256 * cyc), "bank_conflict_cycles": c("SQ_LDS_BANK_CONFLICT"),
-                    "note": "SQ_LDS_IDX_ACTIVE / (256 CUs x busy cycles): the LDS array is not the bound either"},
-                "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU op (MI355X_MICROARCH.md); instruction counts per "
-                        "launch are data-independent without early termination; half of this kernel's opcodes issue at 4 cycles "
-                        "on gfx950 (profiles/r03_ubench_valu_rates.txt), which cycle_weighted accounts for"})
-        if mix and mix.get("valu_ns_per_iteration_all_waves_of_a_row"):
-            # static: disassembly of the loaded kernels x measured per-opcode issue intervals (tools/isa_mix.py): the time the
-            # launch needs if the VALU pipes never idle = VALU-ns of one iteration of one codeword (ns per row-wave set x Z/64
-            # waves), x iterations x codewords, spread over the chip's 1024 SIMDs -- independent of how many codewords a CU holds
-            valu_ms = mix["valu_ns_per_iteration_all_waves_of_a_row"] * (Z / 64.0) * ITERS * batch / 1024.0 * 1e-6
-            roof["cycle_weighted"] = {"valu_bound_ms_per_launch": valu_ms, "frac": valu_ms / kernel_ms,
-                                      "valu_ns_per_iteration_all_waves_of_a_row": mix["valu_ns_per_iteration_all_waves_of_a_row"],
-                                      "source": "profiles/%s_headline_isa_mix.json" % tag}
-        if roof.get("insts_per_launch"):  # every rank decodes the same number of codewords for the same 25 iterations
-            roof["per_gpu"] = [{"rank": r, "kernel_ms": ms, "frac": roof["insts_per_launch"] / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS}
-                               for r, ms in enumerate(kms_all)]
-        else:
-            roof["per_gpu"] = [{"rank": r, "kernel_ms": ms, "frac": None} for r, ms in enumerate(kms_all)]
-        roof["profile"] = {"tag": tag, "nrldpc_kernel_id": kid, "nrldpc_build_id": bid,
-                           "matches_loaded_library": tag is not None,
-                           "source": None if tag is None else "profiles/%s_bench_pmc_summary.json, profiles/%s_bench_kernel_stats.csv "
-                                     "(rocprofv3 --kernel-trace --stats / --pmc, separate passes, of this command)" % (tag, tag)}
-        roof["context"] = {
-            "hbm_streaming_model": {
-                "bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_codeword": ALG_BYTES_PER_CW, "storage_bytes_per_message": S_BYTES,
-                "note": "SURVEY 8(d): bytes a decoder that streams a-posteriori values and messages through HBM every layer "
-                        "would move, at this kernel's storage width (int8); above 1 because a codeword stays in LDS/VGPRs for "
-                        "all %d iterations -- not a fraction of anything this kernel is bound by" % ITERS},
-            "hbm_measured": None if not traffic else {
-                "bytes_per_launch": traffic, "achieved": traffic / (kernel_ms * 1e-3) / 1e9, "unit": "GB/s",
-                "frac_of_peak": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "ratio_to_compulsory": traffic / compulsory, "compulsory_bytes_per_launch": compulsory,
-                "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes: every LLR read once, every "
-                        "hard bit written once, nothing else"}}
-        out = {
-            "metric": "decoded info Gbit/s @ BG1 Z=384 R=1/3, 25 iters; BLER match vs MATLAB ref",
-            "value": value, "unit": "Gbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "comm": comm,
-            "vs_baseline": None, "dtype": "i8 messages / integer-valued f32 a-posteriori (fp16 LLR input)",
-            "data": "synthetic",
-            "config": {"workload": "BG1 Z=384 (K=8448) R=1/3, 25 layered min-sum iterations, no early termination, "
-                                   "batch=%d codewords per GPU, QPSK/AWGN Es/N0=%.1f dB" % (batch, ESN0_DB),
-                       "bg": BG, "Z": Z, "iterations": ITERS, "batch_per_gpu": batch, "n_layers": 46,
-                       "check_node_rule": {"alpha": rule[0], "beta_llr": rule[1], "source": "nrldpc_default_rule (cfg.alpha = 0)"},
-                       "sharding": "codeword batches per GPU, no collective"},
-            "roofline": roof,
-            "bler": bler,
-            "bler_match": bler_match(),
-            "early_term": early,
-            "cfg5_strong": cfg5,
-        }
+        out = build_line(nrldpc, args, world, batch, elapsed, kms, kms_all, rule, bler, early, cfg5, comm.info)
         if world == 1:  # CPU baseline and host-path legs at N = 1 only
             # the host-path leg first: the all-core CPU baselines spend the process's CPU quota (the MI355X boxes grant 16
             # CPUs of the 256 they show) and a throttled process measures the throttle, not the path
@@ -677,9 +794,7 @@ def main():
                 out["e2e"] = e2e
         print(json.dumps(out), flush=True)
     codec.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

@@ -58,8 +58,11 @@ typedef struct nrldpc_codec* nrldpc_handle;
  * nrldpc_cfg).
  * Revision 5 makes the active layer count a property of the CALL, not of the handle: nrldpc_set_layers / nrldpc_last_layers /
  * nrldpc_count_layers / nrldpc_pool_set_layers / nrldpc_set_llr_dtype and the value NRLDPC_LAYERS_AUTO (-1) for nrldpc_cfg.n_layers -- see "Active
- * layers" below; and adds nrldpc_pool_decode_packed.  nrldpc_cfg and nrldpc_dims keep their revision-4 layout and size. */
-#define NRLDPC_ABI_VERSION 5
+ * layers" below; and adds nrldpc_pool_decode_packed.  nrldpc_cfg and nrldpc_dims keep their revision-4 layout and size.
+ * Revision 6 adds nrldpc_decode_packed_layers (the layer count as an ARGUMENT of one call: nothing sticks to the handle) and
+ * nrldpc_pool_set_timing / nrldpc_pool_last_kernel_ms (event-pair kernel times of every shard of a pool); nothing a revision-5
+ * caller uses changed meaning. */
+#define NRLDPC_ABI_VERSION 6
 
 /* Active layers.  The reference always decodes the full H (NRLDPCDecoder.m:120).  A base-graph row i >= 4 owns the degree-1
  * extension-parity column kb + i; when every codeword of a call holds LLR 0 in that column (not transmitted: rate matching
@@ -72,7 +75,12 @@ typedef struct nrldpc_codec* nrldpc_handle;
  *   HARQ-combined buffer because nothing is assumed about how the zeros came about.  Host-pointer entry points scan the caller's
  *   array from the top column down on the copy threads (a column block that is all zero is read once and never quantised or
  *   sent); device-pointer entry points run a pre-pass kernel and read one integer back, i.e. they synchronise `stream` once
- *   before the launch.  With cfg.alpha == 0 the check-node rule follows the count in use (nrldpc_default_rule). */
+ *   before the launch.  With cfg.alpha == 0 the check-node rule follows the count in use (nrldpc_default_rule).
+ *   The count under AUTO is ONE number per call -- the maximum over the call's codewords -- so with cfg.alpha == 0 the rule,
+ *   and through it a codeword's hard decisions and iteration count, can depend on which other codewords share the call
+ *   (leaving rows out is exact; changing the rule is not).  A caller that needs batch-independent results gives the count
+ *   (nrldpc_set_layers / nrldpc_decode_packed_layers: what the patched NRLDPCDecoder.m does, from E_r, k_0 and N_cb) or a
+ *   fixed rule (cfg.alpha != 0). */
 #define NRLDPC_LAYERS_ALL 0
 #define NRLDPC_LAYERS_AUTO (-1)
 
@@ -151,6 +159,13 @@ int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t
  * eighth of the bytes crosses PCIe and the copy into the caller's array: the form a MEX gateway uses (matlab/nrldpc_mex.cpp
  * unpacks into the K x C logical array the reference's comm.LDPCDecoder returns, NRLDPCDecoder.m:265). */
 int nrldpc_decode_packed(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard_packed, int32_t* iters_out);
+/* nrldpc_decode_packed with the active layer count of THIS call as an argument (0 all / 4..rows / NRLDPC_LAYERS_AUTO): the
+ * handle's own count (cfg.n_layers, nrldpc_set_layers) is neither read nor changed, so a HARQ caller that gives the count for
+ * one transmission and omits it for the next gets the handle's default back (ABI revision 6).  The reference's
+ * seam is one call per step: step(obj.hLDPCDecoder, cw_tilde), NRLDPCDecoder.m:265 -- the patched LDPC_coding passes the
+ * count it derives from E_r, k_0 and N_cb (NRLDPC.m:463-543) here. */
+int nrldpc_decode_packed_layers(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard_packed, int32_t* iters_out,
+                                int32_t n_layers);
 
 /* The quantisation nrldpc_decode applies to large host batches while it copies them into its pinned staging
  * buffers (so that 1 byte per LLR crosses PCIe instead of 4): dst[i] = NaN ? 0 : rint(clamp(float(src[i]) * llr_scale,
@@ -196,6 +211,12 @@ int nrldpc_pool_set_layers(nrldpc_pool_handle p, int32_t n_layers);
  * scales with the number of GPUs (the host-pointer form above is bounded by the host's copy bandwidth). */
 int nrldpc_pool_decode_dev(nrldpc_pool_handle p, const void* const* d_llr, const int32_t* batch, uint8_t* const* d_hard,
                            int32_t* const* d_iters);
+/* Kernel timing for a pool (nrldpc_set_timing for every shard's handle): when enabled, each shard records a HIP event pair
+ * around its decode kernel on the shard's own launch stream; nrldpc_pool_last_kernel_ms writes the duration of every shard's
+ * last launch to ms[0 .. n_devices-1] (0 for a shard that had no work).  This is how a one-process, N-GPU caller -- bench.py
+ * --in-process -- gets per-GPU kernel times without a process group. */
+int nrldpc_pool_set_timing(nrldpc_pool_handle p, int32_t enabled);
+int nrldpc_pool_last_kernel_ms(nrldpc_pool_handle p, float* ms);
 int nrldpc_pool_size(nrldpc_pool_handle p); /* number of shards (n_devices of nrldpc_pool_create) */
 /* codewords each shard (entry of device_ids) decoded in the last nrldpc_pool_decode call; counts: [n_devices] */
 int nrldpc_pool_last_split(nrldpc_pool_handle p, int32_t* counts);

@@ -25,7 +25,7 @@ class NRLDPCError(RuntimeError):
     identifier = "ldpc_3gpp_matlab:Error"
 
 
-ABI_VERSION = 5  # NRLDPC_ABI_VERSION of include/nrldpc.h
+ABI_VERSION = 6  # NRLDPC_ABI_VERSION of include/nrldpc.h
 LAYERS_ALL, LAYERS_AUTO = 0, -1  # NRLDPC_LAYERS_*
 
 
@@ -75,7 +75,8 @@ EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev",  "nrldpc_crc_check_
            "nrldpc_set_index", "nrldpc_lifting_size", "nrldpc_default_rule", "nrldpc_strerror", "nrldpc_last_error",
            "nrldpc_version", "nrldpc_build_id", "nrldpc_kernel_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
            "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version", "nrldpc_decode_packed",
-           "nrldpc_set_layers", "nrldpc_set_llr_dtype", "nrldpc_last_layers", "nrldpc_count_layers", "nrldpc_pool_set_layers", "nrldpc_pool_decode_packed"]
+           "nrldpc_set_layers", "nrldpc_set_llr_dtype", "nrldpc_last_layers", "nrldpc_count_layers", "nrldpc_pool_set_layers", "nrldpc_pool_decode_packed",
+           "nrldpc_decode_packed_layers", "nrldpc_pool_set_timing", "nrldpc_pool_last_kernel_ms"]
 
 _lib = None
 
@@ -129,6 +130,9 @@ def load():
     L.nrldpc_get_dims.argtypes = [vp, C.POINTER(Dims)]
     L.nrldpc_decode.argtypes = [vp, vp, i32, vp, vp, vp]
     L.nrldpc_decode_packed.argtypes = [vp, vp, i32, vp, vp]
+    L.nrldpc_decode_packed_layers.argtypes = [vp, vp, i32, vp, vp, i32]
+    L.nrldpc_pool_set_timing.argtypes = [vp, i32]
+    L.nrldpc_pool_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nrldpc_decode_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.nrldpc_quantise_llr.argtypes = [vp, vp, C.c_int64, i32, i32]
     L.nrldpc_decode_multi_dev.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), vp]
@@ -263,9 +267,11 @@ class Codec:
             out += (app,)
         return out[0] if len(out) == 1 else out
 
-    def decode_packed(self, llr, want_iters=False, out=None):
+    def decode_packed(self, llr, want_iters=False, out=None, n_layers=None):
         """nrldpc_decode_packed: hard decisions as [B][ceil(K/8)] bytes, bit k of a codeword in byte k // 8 at bit k % 8
-        (np.unpackbits(out, axis=1, bitorder="little")[:, :K] gives decode()'s array).  out: see decode()."""
+        (np.unpackbits(out, axis=1, bitorder="little")[:, :K] gives decode()'s array).  out: see decode().
+        n_layers: the active layer count of THIS call only (nrldpc_decode_packed_layers: 0 all, 4..rows, LAYERS_AUTO); the
+        handle's own count is untouched."""
         llr = np.ascontiguousarray(llr, self.llr_dtype)
         if llr.size % self.N_cw:
             raise NRLDPCError("llr should hold a whole number of codewords of length %d" % self.N_cw)
@@ -274,7 +280,10 @@ class Codec:
             raise NRLDPCError("out should be a C-contiguous uint8 array of shape (%d, %d)" % (B, (self.K + 7) // 8))
         packed = out if out is not None else np.empty((B, (self.K + 7) // 8), np.uint8)
         iters = np.empty(B, np.int32) if want_iters else None
-        check(self._lib.nrldpc_decode_packed(self._h, _ptr(llr), B, _ptr(packed), _ptr(iters)))
+        if n_layers is None:
+            check(self._lib.nrldpc_decode_packed(self._h, _ptr(llr), B, _ptr(packed), _ptr(iters)))
+        else:
+            check(self._lib.nrldpc_decode_packed_layers(self._h, _ptr(llr), B, _ptr(packed), _ptr(iters), int(n_layers)))
         return (packed, iters) if want_iters else packed
 
     def encode(self, info):
@@ -361,6 +370,16 @@ class CodecPool:
         a_b = (C.c_int32 * n)(*[int(b) for b in batch])
         a_it = (vp * n)(*[vp(int(x) if x else None) for x in d_iters]) if d_iters is not None else None
         check(self._lib.nrldpc_pool_decode_dev(self._p, a_llr, a_b, a_hard, a_it))
+
+    def set_timing(self, on=True):
+        """nrldpc_pool_set_timing: event pairs around every shard's decode kernel, on the shard's own launch stream."""
+        check(self._lib.nrldpc_pool_set_timing(self._p, int(on)))
+
+    def last_kernel_ms(self):
+        """Kernel time of every shard's last launch, ms (nrldpc_pool_last_kernel_ms; 0 for a shard without work)."""
+        out = (C.c_float * len(self.device_ids))()
+        check(self._lib.nrldpc_pool_last_kernel_ms(self._p, out))
+        return [float(v) for v in out]
 
     def last_split(self):
         """Codewords each shard decoded in the last call (uneven under early termination: faster shards pull more)."""

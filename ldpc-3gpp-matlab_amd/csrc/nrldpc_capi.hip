@@ -361,6 +361,8 @@ struct nrldpc_codec {
     // batch counters of the parity-stop kernels that refill their codeword slots (DecArgs::work): a ring, one per launch in flight
     DevBuf<int32_t> d_work;
     unsigned work_seq = 0;
+    static constexpr unsigned kWorkRing = 64;
+    hipEvent_t work_done[kWorkRing] = {}; // recorded behind the launch that took the slot: a slot is reused only once that launch is over
     DevBuf<int32_t> d_best; // NRLDPC_LAYERS_AUTO on device pointers: the pre-pass kernel's result ...
     PinBuf pin_best;        // ... and where the host reads it
     // device tables
@@ -518,11 +520,18 @@ int resolve_layers_dev(nrldpc_codec* h, const void* d_llr, int batch, hipStream_
     return NRLDPC_OK;
 }
 
-// the batch counter of the next launch (null when the ring cannot be allocated: the kernels then run without refilling)
-int32_t* next_work(nrldpc_codec* h) {
-    constexpr unsigned RING = 64;
-    if (h->d_work.reserve(RING) != hipSuccess) return nullptr;
-    return h->d_work.p + (h->work_seq++ % RING);
+// The batch counter of the next parity-stop launch (the persistent kernels' "next codeword", nrldpc_decode_z64p.h), from a ring of
+// 64 per handle.  A slot carries an event recorded behind the launch that used it; a slot whose launch is still running -- more than
+// 64 refilling launches in flight over several streams -- is NOT reset under it: this launch then runs without refilling
+// (null: every workgroup decodes its own codewords), as it does when the ring cannot be allocated.
+int32_t* next_work(nrldpc_codec* h, unsigned* slot) {
+    if (h->d_work.reserve(nrldpc_codec::kWorkRing) != hipSuccess) return nullptr;
+    const unsigned i = h->work_seq % nrldpc_codec::kWorkRing;
+    if (h->work_done[i] && hipEventQuery(h->work_done[i]) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!h->work_done[i] && hipEventCreateWithFlags(&h->work_done[i], hipEventDisableTiming) != hipSuccess) { h->work_done[i] = nullptr; return nullptr; }
+    ++h->work_seq;
+    *slot = i;
+    return h->d_work.p + i;
 }
 
 int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard, int32_t* d_iters, float* d_app,
@@ -530,10 +539,12 @@ int decode_launch(nrldpc_codec* h, const void* d_llr, int batch, uint8_t* d_hard
     const nrldpc::Schedule& s = h->sched;
     nrldpc::DecArgs a = make_dec_args(h, d_llr, batch, d_hard, d_iters, d_app, nl, llr_kind);
     h->last_layers = nl;
-    a.work = next_work(h);
+    unsigned wslot = 0;
+    a.work = a.early_term ? next_work(h, &wslot) : nullptr; // only the parity-stop kernels refill
     begin_timing(h, stream);
     hipError_t e = nrldpc::launch_decode(s.g.bg, a, s.threads, s.lds_bytes, stream);
     end_timing(h, stream);
+    if (a.work) (void)hipEventRecord(h->work_done[wslot], stream);
     if (e != hipSuccess) return hipfail(e, "decode kernel launch");
     return NRLDPC_OK;
 }
@@ -716,6 +727,8 @@ void nrldpc_destroy(nrldpc_handle h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (auto ev : h->work_done)
+        if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < nrldpc_codec::kSlots; ++i) {
         h->pin_in[i].release(); h->pin_out[i].release(); h->pin_it[i].release();
         if (h->xdone[i]) (void)hipEventDestroy(h->xdone[i]);
@@ -947,8 +960,11 @@ int nrldpc_decode_multi_dev(int32_t n, const nrldpc_handle* hs, const void* cons
         nrldpc_codec* h = hs[i];
         nrldpc::DecArgs a = make_dec_args(h, d_llr[i], batch[i], d_hard[i], d_iters ? d_iters[i] : nullptr, nullptr, nls[i]);
         h->last_layers = nls[i];
-        a.work = next_work(h);
-        hipError_t e = nrldpc::launch_decode(h->sched.g.bg, a, h->sched.threads, h->sched.lds_bytes, next_stream());
+        unsigned wslot = 0;
+        a.work = a.early_term ? next_work(h, &wslot) : nullptr;
+        hipStream_t ls = next_stream();
+        hipError_t e = nrldpc::launch_decode(h->sched.g.bg, a, h->sched.threads, h->sched.lds_bytes, ls);
+        if (a.work) (void)hipEventRecord(h->work_done[wslot], ls);
         if (e != hipSuccess) rc = hipfail(e, "decode kernel launch");
     }
     if (fan)
@@ -1274,6 +1290,17 @@ int nrldpc_decode_packed(nrldpc_handle h, const void* llr, int32_t batch, uint8_
     return decode_host(h, llr, batch, hard_packed, iters_out, nullptr, true);
 }
 
+int nrldpc_decode_packed_layers(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard_packed, int32_t* iters_out,
+                                int32_t n_layers) {
+    if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
+    const int saved = h->layers; // the handle is driven by one caller thread: the count of this call, then the handle's own again
+    int rc = nrldpc_set_layers(h, n_layers);
+    if (rc != NRLDPC_OK) return rc;
+    rc = decode_host(h, llr, batch, hard_packed, iters_out, nullptr, true);
+    h->layers = saved;
+    return rc;
+}
+
 } // extern "C"
 
 // ---- multi-GPU pool: N handles, N host threads, a queue of chunks ------------------------------------------------
@@ -1502,6 +1529,33 @@ int nrldpc_pool_decode_dev(nrldpc_pool_handle p, const void* const* d_llr, const
     p->cv_done.wait(lk, [&] { return p->running == 0; });
     p->dev_job = false;
     if (p->rc != NRLDPC_OK) return fail(p->rc, p->err);
+    return NRLDPC_OK;
+    NRLDPC_API_END
+}
+
+int nrldpc_pool_set_timing(nrldpc_pool_handle p, int32_t enabled) {
+    if (!p) return fail(NRLDPC_ERR_ARG, "null pool");
+    std::lock_guard<std::mutex> lk(p->m);
+    for (auto h : p->hs) {
+        const int rc = nrldpc_set_timing(h, enabled);
+        if (rc != NRLDPC_OK) return rc;
+    }
+    return NRLDPC_OK;
+}
+
+int nrldpc_pool_last_kernel_ms(nrldpc_pool_handle p, float* ms) {
+    NRLDPC_API_BEGIN
+    if (!p || !ms) return fail(NRLDPC_ERR_ARG, "null pool/out");
+    std::lock_guard<std::mutex> lk(p->m);
+    for (size_t i = 0; i < p->hs.size(); ++i) {
+        nrldpc_handle h = p->hs[i];
+        ms[i] = 0.0f;
+        if (!h->timing) return fail(NRLDPC_ERR_ARG, "timing is not enabled (nrldpc_pool_set_timing)");
+        if (!h->have_time) continue; // this shard has not launched since timing was enabled
+        DEVICE_SCOPE(h);
+        HIP_TRY(hipEventSynchronize(h->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms[i], h->ev0, h->ev1));
+    }
     return NRLDPC_OK;
     NRLDPC_API_END
 }

@@ -397,9 +397,14 @@ template <int BG, int ZC, bool ETP, int NL = BGT<BG>::ROWS> static hipError_t la
     // NRLDPC_REFILL_MASK=0/1/3 forces every / every second / every fourth iteration (A/B)
     static const int env_mask = getenv("NRLDPC_REFILL_MASK") ? atoi(getenv("NRLDPC_REFILL_MASK")) : -1;
     b.refill_mask = env_mask >= 0 ? env_mask : (G::NCW >= 16 ? 1 : 0);
-    // NRLDPC_REFILL_GRID=<n>: at most n workgroups per launch (tests: a small batch then goes through the refill path; read per call)
+    // NRLDPC_REFILL_GRID=<n>: at most n workgroups per launch -- a TEST hook (a small batch then goes through the refill path; the
+    // tests change it from call to call), looked at only in a process that was started with NRLDPC_TEST_HOOKS set: production launches
+    // read no environment here, and a stray NRLDPC_REFILL_GRID cannot cap them
+    static const bool test_hooks = getenv("NRLDPC_TEST_HOOKS") != nullptr;
     int cap = resident[dev & 63];
-    if (const char* e = getenv("NRLDPC_REFILL_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+    if (test_hooks) {
+        if (const char* e = getenv("NRLDPC_REFILL_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }
+    }
     if (ETP && a.work && !no_refill && cap > 0 && grid > cap) {
         grid = cap;
         hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.work), grid * G::NCW, 1, s);

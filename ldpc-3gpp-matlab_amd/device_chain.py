@@ -49,7 +49,7 @@ class DeviceDecodeChain:
         self.llr_dtype = np.dtype(llr_dtype)
         self.dev = torch.device("cuda", device_id)
         self.device_id = device_id
-        self._codec, self._codec_layers = None, None
+        self._codec, self._codec_layers, self._codec_code = None, None, None
         self._layers_seen = 4
         self.harq = self.b_hat = self.cb_pass = None
 
@@ -65,7 +65,14 @@ class DeviceDecodeChain:
 
     def _codec_for(self, n_layers):
         """One codec for the chain's lifetime; the layer count is a property of the call (nrldpc_set_layers, ABI revision 5)."""
+        if self._codec is not None and self._codec_code != (self.p.BG, self.p.Z_c):
+            # A changed on a plain parameter object between steps: Z_c (or BG) moved, and a codec built for the old pair would read
+            # and write tensors sized for the new one out of bounds (ADVICE r5) -- a new code is a new codec
+            self._codec.close()
+            self._codec = None
         if self._codec is None:
+            self._codec_code = (self.p.BG, self.p.Z_c)
+            self._codec_layers = None
             self._codec = Codec(self.p.BG, self.p.Z_c, max_iter=self.iterations, n_layers=n_layers, early_term=True,
                                 alpha=self.alpha or 0.0, beta=self.beta, llr_scale=self.llr_scale, llr_dtype=self.llr_dtype, device_id=self.device_id,
                                 crc=self.p.code_block_check() if self.crc_stop else None)
@@ -135,6 +142,8 @@ class DeviceEncodeChain:
         params.validate()
         self.p = params
         self.dev = torch.device("cuda", device_id)
+        self._device_id = device_id
+        self._codec_code = (params.BG, params.Z_c)
         self._codec = Codec(params.BG, params.Z_c, max_iter=1, llr_dtype=np.float32, device_id=device_id)
 
     def close(self):
@@ -160,6 +169,10 @@ class DeviceEncodeChain:
         c = torch.empty((n_tb * d.C, d.K), dtype=torch.uint8, device=self.dev)
         self._crc_attach(t, a.data_ptr(), n_tb, c.data_ptr(), s)
         cw = torch.empty((n_tb * d.C, 2 * d.Z_c + d.N), dtype=torch.uint8, device=self.dev)
+        if self._codec_code != (d.BG, d.Z_c):  # A changed on the parameter object: another code, another codec (see DeviceDecodeChain)
+            self._codec.close()
+            self._codec_code = (d.BG, d.Z_c)
+            self._codec = Codec(d.BG, d.Z_c, max_iter=1, llr_dtype=np.float32, device_id=self._device_id)
         self._codec.encode_dev(c.data_ptr(), n_tb * d.C, cw.data_ptr(), s)
         g = torch.empty((n_tb, d.G), dtype=torch.uint8, device=self.dev)
         self._rate_match(t, cw.data_ptr(), n_tb, g.data_ptr(), s)

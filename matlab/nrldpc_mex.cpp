@@ -15,9 +15,10 @@
 //                  BG2's 42 rows, at R = 8/9 5 of BG1's 46); 0 = every row of H, as the reference decodes (NRLDPCDecoder.m:120);
 //                  alpha 0 / omitted = the library's rate-dependent check-node rule (nrldpc_default_rule)
 //   [c_hat, it, nl] = nrldpc_mex('decode', id, cw_tilde [, n_layers])   cw_tilde: (N+2*Z_c) x C double OR single, +inf fillers, 0 punctured;
-//                                                       n_layers: the count of THIS call (a caller that knows its rate -- E_r, k_0,
-//                                                       N_cb of NRLDPC.m:463-543 -- saves the scan AUTO makes: with MATLAB doubles the
-//                                                       host side is bound by reading the array, and the scan reads the zeros once)
+//                                                       n_layers: the count of THIS call ONLY -- the handle keeps its own setting
+//                                                       for calls without it (a caller that knows its rate -- E_r, k_0, N_cb of
+//                                                       NRLDPC.m:463-543: the patched NRLDPCDecoder.LDPC_coding -- saves the scan AUTO
+//                                                       makes: with MATLAB doubles the host side is bound by reading the array)
 //                                                       c_hat: K x C double in {0,1}; it: C x 1 int32 iterations run;
 //                                                       nl: the layer count the call ran with
 //   nrldpc_mex('set_layers', id, n_layers)              the count of the calls that follow (0 all, 4..rows, -1 auto)
@@ -105,7 +106,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         need((nrhs == 3 || nrhs == 4) && (mxIsDouble(prhs[2]) || mxIsSingle(prhs[2])) && !mxIsComplex(prhs[2]),
              "decode needs a handle and a real double or single matrix [and a layer count].");
         nrldpc_handle h = handle_of(prhs[1]);
-        if (nrhs == 4) check(nrldpc_set_layers(h, (int32_t)mxGetScalar(prhs[3])));
         nrldpc_dims d;
         d.struct_size = sizeof d;
         check(nrldpc_get_dims(h, &d));
@@ -117,7 +117,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const size_t KB8 = ((size_t)d.K + 7) / 8;
         std::vector<uint8_t> packed(KB8 * (size_t)(C > 0 ? C : 1));
         mxArray* it = mxCreateNumericMatrix(C, 1, mxINT32_CLASS, mxREAL);
-        check(nrldpc_decode_packed(h, mxGetData(prhs[2]), C, packed.data(), (int32_t*)mxGetData(it)));
+        // the 4th argument is the count of THIS call (nrldpc_decode_packed_layers, ABI revision 6): nothing sticks to the handle, so a
+        // retransmission that omits it runs under the handle's own setting again ('create' / 'set_layers': AUTO by default)
+        if (nrhs == 4) check(nrldpc_decode_packed_layers(h, mxGetData(prhs[2]), C, packed.data(), (int32_t*)mxGetData(it), (int32_t)mxGetScalar(prhs[3])));
+        else check(nrldpc_decode_packed(h, mxGetData(prhs[2]), C, packed.data(), (int32_t*)mxGetData(it)));
         plhs[0] = mxCreateDoubleMatrix(d.K, C, mxREAL);                // K x C double {0,1}, what double(step(...)) gives, :265
         double* o = mxGetPr(plhs[0]);
         for (int c = 0; c < C; ++c)

@@ -137,6 +137,22 @@ int main(int argc, char** argv) {
     nrldpc_destroy(h2);
     CHECK(h_auto == h_exp && h_auto == h_new && it_auto == it_exp && it_auto == it_new, "AUTO == set_layers == create(n_layers), bits and counts");
     CHECK(nrldpc_set_layers(h, 3) == NRLDPC_ERR_UNSUPPORTED && nrldpc_set_layers(h, rows + 1) == NRLDPC_ERR_UNSUPPORTED, "invalid counts are refused");
+    // ABI revision 6: the count as an ARGUMENT of one call (what the gateway's 'decode' with a 4th argument calls): the handle, set to
+    // every row here, keeps that setting -- a retransmission that omits the count is decoded with all rows again
+    CHECK(nrldpc_set_layers(h, NRLDPC_LAYERS_ALL) == NRLDPC_OK, "handle back to every row");
+    std::vector<uint8_t> pk_call(KB8 * C, 0xee), pk_all(KB8 * C, 0xdd);
+    std::vector<int32_t> it_call(C, -5);
+    CHECK(nrldpc_decode_packed_layers(h, rm.data(), C, pk_call.data(), it_call.data(), act) == NRLDPC_OK, "nrldpc_decode_packed_layers");
+    CHECK(nrldpc_last_layers(h, &nl) == NRLDPC_OK && nl == act && it_call == it_exp, "the call ran with its own count");
+    for (int c = 0; c < C; ++c)
+        for (size_t k = 0; k < K; ++k)
+            CHECK(((pk_call[(size_t)c * KB8 + (k >> 3)] >> (k & 7)) & 1) == h_exp[(size_t)c * K + k], "per-call count: the bits of set_layers(act)");
+    CHECK(nrldpc_decode_packed(h, llr.data(), C, pk_all.data(), nullptr) == NRLDPC_OK && nrldpc_last_layers(h, &nl) == NRLDPC_OK && nl == rows,
+          "the next call without a count runs under the handle's own setting: nothing stuck");
+    CHECK(std::memcmp(pk_all.data(), packed.data(), packed.size()) == 0, "... and gives the all-rows bits");
+    CHECK(nrldpc_decode_packed_layers(h, rm.data(), C, pk_call.data(), nullptr, NRLDPC_LAYERS_AUTO) == NRLDPC_OK && nrldpc_last_layers(h, &nl) == NRLDPC_OK && nl == act,
+          "per-call AUTO");
+    CHECK(nrldpc_decode_packed_layers(h, rm.data(), C, pk_call.data(), nullptr, 3) == NRLDPC_ERR_UNSUPPORTED, "an invalid per-call count is refused");
 
     // a caller built against ABI revision 3 (nrldpc_cfg without the crc_* tail) is refused, not misread
     nrldpc_cfg old = cfg;
@@ -158,6 +174,13 @@ int main(int argc, char** argv) {
     CHECK(nrldpc_pool_decode_packed(pool, llr.data(), C, p_packed.data(), p_it.data()) == NRLDPC_OK, "nrldpc_pool_decode_packed");
     CHECK(std::memcmp(p_packed.data(), packed.data(), packed.size()) == 0 && p_it == it2, "pool, bit-packed == handle, bit-packed");
     CHECK(nrldpc_pool_set_layers(pool, 0) == NRLDPC_OK && nrldpc_pool_set_layers(pool, 2) == NRLDPC_ERR_UNSUPPORTED, "nrldpc_pool_set_layers");
+    // ABI revision 6: per-shard kernel times of a pool (event pairs on the shards' own streams)
+    float pms[2] = {-1.0f, -1.0f};
+    CHECK(nrldpc_pool_last_kernel_ms(pool, pms) == NRLDPC_ERR_ARG, "no pool timing before it is enabled");
+    CHECK(nrldpc_pool_set_timing(pool, 1) == NRLDPC_OK, "nrldpc_pool_set_timing");
+    CHECK(nrldpc_pool_decode(pool, llr.data(), C, p_hard.data(), p_it.data()) == NRLDPC_OK, "a timed pool call");
+    CHECK(nrldpc_pool_last_kernel_ms(pool, pms) == NRLDPC_OK && pms[0] >= 0.0f && pms[1] >= 0.0f && pms[0] + pms[1] > 0.0f, "nrldpc_pool_last_kernel_ms");
+    CHECK(nrldpc_pool_set_timing(pool, 0) == NRLDPC_OK, "pool timing off");
     nrldpc_pool_destroy(pool);
     nrldpc_destroy(h);
     std::printf("{\"bg\": %d, \"Z\": %d, \"C\": %d, \"EsN0_dB\": %.2f, \"block_errors\": %d, \"max_iterations\": %d, "

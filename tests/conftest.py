@@ -5,6 +5,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("NRLDPC_TEST_HOOKS", "1")  # the library reads its test-only knobs (NRLDPC_REFILL_GRID) only under this
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -113,7 +113,10 @@ def test_matlab_patch_applies(tmp_path):
     patch = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "matlab", "ldpc-3gpp-matlab.patch")
     subprocess.check_call(["patch", "-p1", "--binary", "-s", "-i", patch], cwd=tmp_path)
     dec = (tmp_path / "NRLDPCDecoder.m").read_text(encoding="latin-1")
-    assert "nrldpc_mex('decode', obj.hLDPCDecoder, cw_tilde)" in dec and "comm.LDPCDecoder(" not in dec
+    assert "nrldpc_mex('decode', obj.hLDPCDecoder, cw_tilde, n_layers)" in dec and "comm.LDPCDecoder(" not in dec
+    # the exact active-row count goes with every call: derived from E_r / k_0 / N_cb, sticky while HARQ state is
+    # pending, cleared by setupImpl and resetImpl (tests/test_testbench.py checks the arithmetic against NRLDPC_LAYERS_AUTO)
+    assert dec.count("function n_layers = active_layers(obj)") == 1 and dec.count("obj.layers_seen = 0;") == 2
     assert "nrldpc_mex('encode'" in (tmp_path / "NRLDPCEncoder.m").read_text(encoding="latin-1")
     enc = (tmp_path / "NRLDPCEncoder.m").read_text(encoding="latin-1")
     assert enc.count("releaseImpl") == 1 and dec.count("function releaseImpl") == 1  # both objects give their codec back
@@ -141,9 +144,9 @@ def test_abi_revision_and_struct_size_guard(pkg):
     read or written."""
     C = pkg._capi
     lib = pkg.load()
-    assert lib.nrldpc_abi_version() == C.ABI_VERSION == 5
+    assert lib.nrldpc_abi_version() == C.ABI_VERSION == 6
     hdr = open(os.path.join(ROOT, "include", "nrldpc.h")).read()
-    assert "#define NRLDPC_ABI_VERSION 5" in hdr and "#define NRLDPC_LAYERS_AUTO (-1)" in hdr
+    assert "#define NRLDPC_ABI_VERSION 6" in hdr and "#define NRLDPC_LAYERS_AUTO (-1)" in hdr
     cfg = C.Cfg(1, 384, 0, 10, 1, 0.0, 0, 0, 0, 0)
     assert cfg.struct_size == ctypes.sizeof(C.Cfg)
     cfg.struct_size = ctypes.sizeof(C.Cfg) - 4  # the r1 layout (no beta)

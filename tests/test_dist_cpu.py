@@ -113,9 +113,38 @@ def test_bench_starts_its_own_ranks_and_refuses_a_wrong_rank_count():
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["comm"] == {"backend": "gloo", "world_size": 2}
+    assert rec["n_gpus"] == 2 and rec["comm"]["backend"] == "gloo" and rec["comm"]["world_size"] == 2 and rec["comm"]["fallback"] is None
     assert [g["codewords"] for g in rec["cfg5_strong"]["per_gpu"]] == [32768, 32768]
     for world in ("1", "4"):
         q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True,
                            timeout=120, cwd=ROOT, env=dict(env, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0"))
         assert q.returncode != 0 and "--gpus 8 but WORLD_SIZE=" + world in q.stderr and "{" not in q.stdout
+
+
+def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up():
+    """the data path needs no collective, so a run must not be lost to RCCL.  bench.py's default `--backend nccl`
+    PROBES RCCL (second process group, one all-reduce, time limit) over a gloo default group and uses it only when every rank's probe
+    succeeded.  Here -- two CPU processes, no HIP device -- the probe fails on every rank: the protocol completes over gloo and the
+    line says what was asked for, what carried the barrier, and why."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)  # no --backend: the driver's form
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ms_per_step"] >= 2.0
+    assert rec["comm"]["requested"] == "nccl" and rec["comm"]["backend"] == "gloo" and rec["comm"]["fallback"]
+    assert [g["codewords"] for g in rec["cfg5_strong"]["per_gpu"]] == [32768, 32768]
+
+
+def test_in_process_form_is_refused_under_a_launcher():
+    """`bench.py --gpus N --in-process` is the one-process route (nrldpc_pool_decode_dev); started under a launcher it would run N
+    times: refused, no JSON line."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--in-process"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT, env=env)
+    assert q.returncode != 0 and "--in-process" in q.stderr and "{" not in q.stdout

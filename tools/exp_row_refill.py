@@ -3,6 +3,7 @@
 stop.  Parity against the oracle with the workgroups capped (NRLDPC_REFILL_GRID), then the stop's time at the size's waterfall.
 NRLDPC_LIB selects the library.  python tools/exp_row_refill.py bg,Z ..."""
 import importlib, os, sys, json
+os.environ.setdefault("NRLDPC_TEST_HOOKS", "1")  # NRLDPC_REFILL_GRID is read only under this (nrldpc_decode_z64p.h)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))

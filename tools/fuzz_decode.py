@@ -10,6 +10,7 @@ MULTI=1: nrldpc_decode_multi_dev -- each case one call over 2 ... 14 configurati
 fp16 or fp32 LLRs, 1 ... 90 codewords each, a bucket now and then large enough for a launch of its own), every configuration against the oracle:
 the shared launches' workgroup classes and prefix tables, the routing, the per-handle layer counts."""
 import importlib, os, sys
+os.environ.setdefault("NRLDPC_TEST_HOOKS", "1")  # NRLDPC_REFILL_GRID is read only under this (nrldpc_decode_z64p.h)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
