@@ -60,8 +60,8 @@ typedef struct nrldpc_codec* nrldpc_handle;
  * nrldpc_count_layers / nrldpc_pool_set_layers / nrldpc_set_llr_dtype and the value NRLDPC_LAYERS_AUTO (-1) for nrldpc_cfg.n_layers -- see "Active
  * layers" below; and adds nrldpc_pool_decode_packed.  nrldpc_cfg and nrldpc_dims keep their revision-4 layout and size.
  * Revision 6 adds nrldpc_decode_packed_layers (the layer count as an ARGUMENT of one call: nothing sticks to the handle) and
- * nrldpc_pool_set_timing / nrldpc_pool_last_kernel_ms (event-pair kernel times of every shard of a pool); nothing a revision-5
- * caller uses changed meaning. */
+ * nrldpc_pool_set_timing / nrldpc_pool_last_kernel_ms (event-pair kernel times of every shard of a pool) and
+ * nrldpc_last_host_phases (the phase times of a large host-pointer call); nothing a revision-5 caller uses changed meaning. */
 #define NRLDPC_ABI_VERSION 6
 
 /* Active layers.  The reference always decodes the full H (NRLDPCDecoder.m:120).  A base-graph row i >= 4 owns the degree-1
@@ -290,6 +290,12 @@ int nrldpc_awgn_llr_dev(const uint8_t* d_g, int64_t n_bits, int32_t Q_m, float E
  * launch stream; nrldpc_last_kernel_ms synchronises on the stop event and returns the duration. */
 int nrldpc_set_timing(nrldpc_handle h, int32_t enabled);
 int nrldpc_last_kernel_ms(nrldpc_handle h, float* ms);
+/* Where the handle's last LARGE host-pointer call (nrldpc_decode / nrldpc_decode_packed[_layers] above 8 MB: the chunked pipeline)
+ * spent its time -- what NRLDPC_HOST_TRACE=1 prints, as numbers (ABI revision 6): out10[0] chunks, [1] codewords per chunk, [2] layers
+ * decoded, then milliseconds of the CALLER's thread: [3] NRLDPC_LAYERS_AUTO scan, [4] copy / quantise into pinned memory incl. the
+ * H2D enqueue, [5] kernel launch + D2H enqueue, [6] waiting for the device, [7] copying results out; [8] NUMA node the copy
+ * threads are pinned to, [9] CPU the caller ran on.  NRLDPC_ERR_ARG when no such call has been made on the handle. */
+int nrldpc_last_host_phases(nrldpc_handle h, double* out10);
 
 /* Check-node rule nrldpc_create applies when cfg.alpha == 0, by base graph and active layer count (0 = all):
  * the (alpha, beta) pair measured closest to flooding sum-product (the reference's comm.LDPCDecoder,

@@ -76,7 +76,7 @@ EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev",  "nrldpc_crc_check_
            "nrldpc_version", "nrldpc_build_id", "nrldpc_kernel_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
            "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version", "nrldpc_decode_packed",
            "nrldpc_set_layers", "nrldpc_set_llr_dtype", "nrldpc_last_layers", "nrldpc_count_layers", "nrldpc_pool_set_layers", "nrldpc_pool_decode_packed",
-           "nrldpc_decode_packed_layers", "nrldpc_pool_set_timing", "nrldpc_pool_last_kernel_ms"]
+           "nrldpc_decode_packed_layers", "nrldpc_pool_set_timing", "nrldpc_pool_last_kernel_ms", "nrldpc_last_host_phases"]
 
 _lib = None
 
@@ -132,6 +132,7 @@ def load():
     L.nrldpc_decode_packed.argtypes = [vp, vp, i32, vp, vp]
     L.nrldpc_decode_packed_layers.argtypes = [vp, vp, i32, vp, vp, i32]
     L.nrldpc_pool_set_timing.argtypes = [vp, i32]
+    L.nrldpc_last_host_phases.argtypes = [vp, C.POINTER(C.c_double)]
     L.nrldpc_pool_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nrldpc_decode_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.nrldpc_quantise_llr.argtypes = [vp, vp, C.c_int64, i32, i32]
@@ -305,6 +306,15 @@ class Codec:
 
     def set_timing(self, on=True):
         check(self._lib.nrldpc_set_timing(self._h, int(on)))
+
+    def last_host_phases(self):
+        """nrldpc_last_host_phases as a dict (ms of the caller's thread in each phase of the last large host-pointer call), or None."""
+        out = (C.c_double * 10)()
+        if self._lib.nrldpc_last_host_phases(self._h, out) != 0:
+            return None
+        return {"chunks": int(out[0]), "codewords_per_chunk": int(out[1]), "layers": int(out[2]), "scan_ms": out[3],
+                "copy_quantise_ms": out[4], "launch_enqueue_ms": out[5], "wait_device_ms": out[6], "copy_out_ms": out[7],
+                "copy_threads_numa_node": int(out[8]), "caller_cpu": int(out[9])}
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -361,6 +361,7 @@ struct nrldpc_codec {
     // batch counters of the parity-stop kernels that refill their codeword slots (DecArgs::work): a ring, one per launch in flight
     DevBuf<int32_t> d_work;
     unsigned work_seq = 0;
+    double host_phases[10] = {}; // of the last chunked host-pointer call (nrldpc_last_host_phases); [0] = 0: none yet
     static constexpr unsigned kWorkRing = 64;
     hipEvent_t work_done[kWorkRing] = {}; // recorded behind the launch that took the slot: a slot is reused only once that launch is over
     DevBuf<int32_t> d_best; // NRLDPC_LAYERS_AUTO on device pointers: the pre-pass kernel's result ...
@@ -798,6 +799,13 @@ int nrldpc_last_kernel_ms(nrldpc_handle h, float* ms) {
     return NRLDPC_OK;
 }
 
+int nrldpc_last_host_phases(nrldpc_handle h, double* out10) {
+    if (!h || !out10) return fail(NRLDPC_ERR_ARG, "null handle/out");
+    if (h->host_phases[0] == 0) return fail(NRLDPC_ERR_ARG, "no chunked host-pointer call recorded on this handle");
+    for (int i = 0; i < 10; ++i) out10[i] = h->host_phases[i];
+    return NRLDPC_OK;
+}
+
 int nrldpc_decode_dev(nrldpc_handle h, const void* d_llr, int32_t batch, uint8_t* d_hard, int32_t* d_iters_out,
                       float* d_app_out, void* stream) {
     if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
@@ -1195,6 +1203,11 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             t_enq += now();
         }
         while (drained < nchunks) { int rc = drain_step((size_t)-1, true); if (rc) return rc; }
+        {
+            double* ph = h->host_phases;
+            ph[0] = nchunks; ph[1] = chunk; ph[2] = nl; ph[3] = t_scan; ph[4] = t_quant; ph[5] = t_enq; ph[6] = t_wait; ph[7] = t_out;
+            ph[8] = h->pool->node_; ph[9] = sched_getcpu();
+        }
         if (trace)
             fprintf(stderr, "[nrldpc host path] %d chunks of %d, %d layers (%zu of %zu LLRs per codeword on the wire; scan %.2f ms): copy/quantise in %.2f ms (incl. H2D enqueue), launch+D2H enqueue %.2f, wait for device %.2f, copy out %.2f; copy threads on NUMA node %d (caller on CPU %d)\n",
                     nchunks, chunk, nl, act, ncw, t_scan, t_quant, t_enq, t_wait, t_out, h->pool->node_, sched_getcpu());

@@ -798,6 +798,29 @@ __device__ __forceinline__ void pipeline_z64(GroupZ64<BG, ZC, GI, NL>& cur, Grou
 #endif
 }
 
+// N values live in registers at one point of the program, behind a compiler-level memory fence: every load that produced them has
+// been issued before it, none of the loads after it has (the LDS reads of a parity check go out in batches of N, neither one round
+// trip per edge nor all nineteen of a dense row at once)
+template <int N> __device__ __forceinline__ void pin_batch(uint32_t (&v)[8]) {
+    static_assert(N >= 1 && N <= 8, "batch size");
+    if constexpr (N == 1) asm volatile("" : "+v"(v[0]) : : "memory");
+    else if constexpr (N == 2) asm volatile("" : "+v"(v[0]), "+v"(v[1]) : : "memory");
+    else if constexpr (N == 3) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]) : : "memory");
+    else if constexpr (N == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+    else if constexpr (N == 5) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]) : : "memory");
+    else if constexpr (N == 6) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : : "memory");
+    else if constexpr (N == 7) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]) : : "memory");
+    else asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+}
+
+// Parity of check row L on the signs of the a-posteriori values.  The row's LDS reads go out in batches of up to NRLDPC_PARITY_BATCH
+// (pin_batch): left alone, the compiler of this ROCm release either waited for every read before issuing the next (one LDS round
+// trip per edge) or -- dense rows of BG1 under the 80-VGPR budget of the split kernels -- issued all nineteen and parked them in
+// SCRATCH one by one (16 spilled registers in <1, 384, ETP>: 75 MB of the 109 MB that launch wrote to HBM were these, round 6;
+// profiles/r06_parity_pass_read_batching.txt: -1 ... -5 % of the stop's time at the waterfall).  -DNRLDPC_PARITY_BATCH=0: as before (A/B).
+#ifndef NRLDPC_PARITY_BATCH
+#define NRLDPC_PARITY_BATCH 6
+#endif
 template <int BG, int ZC, int L>
 __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R)[Z64<BG, ZC>::NBASE], uint32_t esign_lo,
                                                    uint32_t esign_hi) {
@@ -806,12 +829,31 @@ __device__ __forceinline__ uint32_t row_parity_z64(char* lds, const uint32_t (&R
     constexpr int deg = G::row_ptr(L + 1) - e0;
     constexpr bool HAS_EXT = (L >= 4);
     constexpr int ncore = deg - (HAS_EXT ? 1 : 0);
+    constexpr int CH = NRLDPC_PARITY_BATCH > 0 ? NRLDPC_PARITY_BATCH : 8;
+    static_assert(NRLDPC_PARITY_BATCH >= 0 && CH <= 8, "NRLDPC_PARITY_BATCH");
     uint32_t p = 0;
-    static_for<ncore>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int c = G::col(e0 + j);
-        constexpr int P = G::shift(e0 + j);
-        p ^= fbits(*reinterpret_cast<const float*>(lds + R[G::pb(c, P)] + G::po(c, P)));
+    if constexpr (NRLDPC_PARITY_BATCH == 0) { // A/B: the reads left to the compiler (rounds 1-5)
+        static_for<ncore>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int c = G::col(e0 + j);
+            constexpr int P = G::shift(e0 + j);
+            p ^= fbits(*reinterpret_cast<const float*>(lds + R[G::pb(c, P)] + G::po(c, P)));
+        });
+    } else static_for<(ncore + CH - 1) / CH>([&](auto bc) {
+        constexpr int b0 = decltype(bc)::value * CH;
+        constexpr int n = ncore - b0 < CH ? ncore - b0 : CH;
+        uint32_t v[8];
+        static_for<n>([&](auto ic) {
+            constexpr int j = b0 + decltype(ic)::value;
+            constexpr int c = G::col(e0 + j);
+            constexpr int P = G::shift(e0 + j);
+            v[decltype(ic)::value] = fbits(*reinterpret_cast<const float*>(lds + R[G::pb(c, P)] + G::po(c, P)));
+        });
+        pin_batch<n>(v);
+        static_for<n>([&](auto ic) { p ^= v[decltype(ic)::value]; });
+        // ... and the batch is folded before the next one is read (the fence again, now behind the xors: without it the scheduler
+        // issued the next batch's reads first and parked this batch's values in scratch until "later")
+        if constexpr (b0 + n < ncore) asm volatile("" : "+v"(p) : : "memory");
     });
     p >>= 31;
     if constexpr (HAS_EXT) p ^= (L - 4 < 32 ? esign_lo >> ((L - 4) & 31) : esign_hi >> ((L - 36) & 31)) & 1u;

@@ -181,6 +181,157 @@ __global__ __launch_bounds__(256) void nrldpc_rate_recover_fast_kernel(const RmA
     }
 }
 
+// ---- round 6: the no-repetition case INPUT-driven (serves calls with a HARQ buffer at Q_m <= 2: launch_rate_recover) ----------------
+// The gather above reads g_tilde at a stride: the two positions of an output pair are neighbours in e, and e(i*rows + j) = f(j*Qm + i)
+// puts neighbours Qm floats apart, so a wave's load instruction uses 1/Qm ... 1/(2 Qm) of every line it touches and the kernel sat at
+// 0.53 of the HBM roofline with 79 % of its wave-cycles waiting (profiles/r05_stage_kernels_pmc.txt).  Here a lane owns J consecutive
+// interleaver columns j of ALL Qm rows: J*Qm consecutive floats of g_tilde, read as whole 16-byte words (a wave instruction = one
+// contiguous kilobyte, every byte used), and scatters them: row i's J values are J neighbouring positions of the circular buffer
+// (unless the run crosses its end or the filler gap), i.e. Qm short contiguous stores per lane, each wave-store a contiguous run.
+// Positions that receive nothing -- the 2Z punctured columns, fillers (+inf), what lies beyond E or beyond N_cb -- are written by a
+// second set of waves of the same launch that only store (with HARQ: echo the buffer).  Same values as the gather: without
+// repetition a position takes exactly one e(k) or none, so there is no order of additions to preserve.
+template <int QM> struct RrJ { static constexpr int J = QM == 1 ? 4 : (QM == 2 || QM == 6) ? 2 : 1; };
+typedef float __attribute__((ext_vector_type(4), aligned(4))) float4_a4; // 16-byte load that only needs dword alignment
+constexpr int RR_FILL_TILE = 512;                                          // positions per wave of the fill part: 4 sweeps of 64 pairs
+
+template <typename OutT, int QM>
+__global__ __launch_bounds__(256) void nrldpc_rate_recover_scatter_kernel(const RmArgs a, const int in_blocks) {
+    constexpr int J = RrJ<QM>::J, NV = J * QM; // floats per lane
+    const int blk = blockIdx.y;
+    const int tb = blk / a.C, r = blk - tb * a.C;
+    const int ncwz = 2 * a.Z + a.N;
+    const int lo_f = a.Kp - 2 * a.Z > 0 ? a.Kp - 2 * a.Z : 0, hi_f = a.K - 2 * a.Z;
+    const int f_hi = hi_f < a.N_cb ? hi_f : a.N_cb;
+    const int F = f_hi > lo_f ? f_hi - lo_f : 0;
+    const int P = a.N_cb - F;
+    int nfk0 = a.k0 - lo_f;
+    nfk0 = a.k0 - (nfk0 < 0 ? 0 : (nfk0 > F ? F : nfk0));
+    const int E = a.E[r];
+    const int rows = E / QM;
+    float* hb = a.harq ? a.harq + (size_t)blk * a.N_cb : nullptr;
+    OutT* out = static_cast<OutT*>(a.out) + (size_t)blk * ncwz;
+    if ((int)blockIdx.x < in_blocks) {
+        // ---- input part: lane -> columns j0 .. j0+J-1
+        const int j0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * J;
+        if (j0 >= rows) return;
+        const float* f = a.g + (size_t)tb * a.G + a.off[r] + (size_t)j0 * QM;
+        const int nj = rows - j0 < J ? rows - j0 : J;
+        float v[NV];
+        if (nj == J) {
+            if constexpr (NV % 4 == 0) {
+#pragma unroll
+                for (int k = 0; k < NV / 4; ++k) {
+                    const float4_a4 w = reinterpret_cast<const float4_a4*>(f)[k];
+                    v[4 * k] = w.x; v[4 * k + 1] = w.y; v[4 * k + 2] = w.z; v[4 * k + 3] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[k] = f[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = k < nj * QM ? f[k] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < QM; ++i) {
+            // non-filler index of e(i*rows + j0) counted from 0, then its position in d (fillers skipped), then in the core's input
+            int n = i * rows + j0 + nfk0;
+            n -= n >= P ? P : 0;
+            const int p = n < lo_f ? n : n + F;
+            // the J values are neighbours in d unless the run crosses the end of the buffer or the filler gap
+            const bool run = nj == J && n + J <= P && (n >= lo_f || n + J <= lo_f);
+            if (run) {
+                float val[J];
+#pragma unroll
+                for (int t = 0; t < J; ++t) val[t] = v[t * QM + i];
+                if (hb) { // NRLDPCDecoder.m:236-239
+#pragma unroll
+                    for (int t = 0; t < J; ++t) { val[t] += hb[p + t]; hb[p + t] = val[t]; }
+                }
+                OutT* o = out + 2 * a.Z + p;
+                if constexpr (J == 1) {
+                    o[0] = to_out<OutT>(val[0]);
+                } else if constexpr (J == 2) {
+                    struct alignas(2 * sizeof(OutT)) Pair { OutT x, y; };
+                    if ((reinterpret_cast<uintptr_t>(o) & (2 * sizeof(OutT) - 1)) == 0) *reinterpret_cast<Pair*>(o) = Pair{to_out<OutT>(val[0]), to_out<OutT>(val[1])};
+                    else { o[0] = to_out<OutT>(val[0]); o[1] = to_out<OutT>(val[1]); }
+                } else {
+                    struct alignas(4 * sizeof(OutT)) Quad { OutT x, y, z, w; };
+                    if ((reinterpret_cast<uintptr_t>(o) & (4 * sizeof(OutT) - 1)) == 0)
+                        *reinterpret_cast<Quad*>(o) = Quad{to_out<OutT>(val[0]), to_out<OutT>(val[1]), to_out<OutT>(val[2]), to_out<OutT>(val[3])};
+                    else {
+#pragma unroll
+                        for (int t = 0; t < J; ++t) o[t] = to_out<OutT>(val[t]);
+                    }
+                }
+            } else {
+                for (int t = 0; t < nj; ++t) {
+                    int nn = n + t;
+                    nn -= nn >= P ? P : 0;
+                    const int pp = nn < lo_f ? nn : nn + F;
+                    float val = v[t * QM + i];
+                    if (hb) { val += hb[pp]; hb[pp] = val; }
+                    out[2 * a.Z + pp] = to_out<OutT>(val);
+                }
+            }
+        }
+        return;
+    }
+    // ---- fill part: positions no e(k) lands on.  Pairs of neighbouring positions per lane as in the gather kernels, whole tiles of
+    // covered positions skipped by a wave-uniform test (at R = 1/3 without fillers only the 2Z punctured columns are left).
+    const int wave = ((int)blockIdx.x - in_blocks) * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile0 = wave * RR_FILL_TILE;
+    if (tile0 >= ncwz) return;
+    // d positions [c0, c1) (cyclically, in non-filler index space [n0, n0 + E)) are covered
+    auto covered = [&](int p) -> bool { // p: position in d, 0 <= p < N_cb, not a filler
+        int c = p - lo_f;
+        c = c < 0 ? 0 : (c > F ? F : c);
+        int q = p - c - nfk0;
+        q += q < 0 ? P : 0;
+        return q < E;
+    };
+    {
+        // wave-uniform skip: the tile lies inside one stretch of d between two boundaries and that stretch is covered
+        const int x0 = tile0, x1 = (tile0 + RR_FILL_TILE < ncwz ? tile0 + RR_FILL_TILE : ncwz) - 1; // inclusive
+        const int p0 = x0 - 2 * a.Z, p1 = x1 - 2 * a.Z;
+        bool plain = p0 >= 0 && p1 < a.N_cb && !(p1 >= lo_f && p0 < hi_f); // no punctured column, nothing beyond the buffer, no filler
+        if (plain) {
+            // covered positions form a cyclic interval of non-filler indices: both ends covered and the same distance apart in q as in p
+            int c0 = p0 - lo_f; c0 = c0 < 0 ? 0 : (c0 > F ? F : c0);
+            int c1 = p1 - lo_f; c1 = c1 < 0 ? 0 : (c1 > F ? F : c1);
+            int q0 = p0 - c0 - nfk0; q0 += q0 < 0 ? P : 0;
+            int q1 = p1 - c1 - nfk0; q1 += q1 < 0 ? P : 0;
+            if (q0 < E && q1 < E && q1 - q0 == p1 - p0) return;
+        }
+    }
+    const bool vec = (ncwz % 2) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7) == 0;
+#pragma unroll
+    for (int s = 0; s < RR_FILL_TILE / 128; ++s) {
+        const int pos0 = tile0 + s * 128 + 2 * lane;
+        if (pos0 >= ncwz) break;
+        bool skip[2];
+        OutT o[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int p = pos0 + t - 2 * a.Z;
+            const bool filler = p >= lo_f && p < hi_f;
+            const bool inbuf = p >= 0 && p < a.N_cb && !filler;
+            skip[t] = (inbuf && covered(p)) || pos0 + t >= ncwz;
+            float val = 0.0f;
+            if (hb && inbuf && !skip[t]) val = hb[p]; // :236-239 with nothing received: the buffer as it is
+            o[t] = to_out<OutT>(filler ? __builtin_inff() : val);
+        }
+        if (vec && !skip[0] && !skip[1]) {
+            struct alignas(2 * sizeof(OutT)) Pair { OutT x, y; };
+            *reinterpret_cast<Pair*>(out + pos0) = Pair{o[0], o[1]};
+        } else {
+            if (!skip[0]) out[pos0] = o[0];
+            if (!skip[1]) out[pos0 + 1] = o[1];
+        }
+    }
+}
+
 // Transmit side: bit selection + interleaving + concatenation (NRLDPCEncoder.m:168-256) as one gather.
 // Output bit x of code block r is f(x) = e(i*E/Qm + j) with i = x mod Qm, j = x div Qm (:219-223), and
 // e(k) is the (k mod P)-th non-filler position of the circular buffer counted from k_0 (:186-195).
@@ -292,6 +443,24 @@ template <typename OutT> static void launch_rr_fast(const RmArgs& a, dim3 grid, 
     }
 }
 
+template <typename OutT> static void launch_rr_scatter(const RmArgs& a, int emax, hipStream_t stream) {
+    const int ncwz = 2 * a.Z + a.N;
+    const int fill_blocks = (ncwz + 4 * RR_FILL_TILE - 1) / (4 * RR_FILL_TILE);
+    auto go = [&](auto qc) {
+        constexpr int QM = decltype(qc)::value;
+        const int rows = emax / QM;
+        const int in_blocks = (rows + 256 * RrJ<QM>::J - 1) / (256 * RrJ<QM>::J);
+        hipLaunchKernelGGL((nrldpc_rate_recover_scatter_kernel<OutT, QM>), dim3(in_blocks + fill_blocks, a.n_tb * a.C), dim3(256), 0, stream, a, in_blocks);
+    };
+    switch (a.Qm) {
+        case 1: go(std::integral_constant<int, 1>{}); break;
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 6: go(std::integral_constant<int, 6>{}); break;
+        default: go(std::integral_constant<int, 8>{}); break;
+    }
+}
+
 hipError_t launch_rate_recover(const RmArgs& a, hipStream_t stream) {
     const int ncwz = 2 * a.Z + a.N;
     const int per_block = 4 * RR_TILE;
@@ -300,10 +469,20 @@ hipError_t launch_rate_recover(const RmArgs& a, hipStream_t stream) {
     const int lo_f = a.Kp - 2 * a.Z > 0 ? a.Kp - 2 * a.Z : 0, hi_f = a.K - 2 * a.Z;
     const int f_hi = hi_f < a.N_cb ? hi_f : a.N_cb;
     const int P = a.N_cb - (f_hi > lo_f ? f_hi - lo_f : 0);
-    bool repeats = getenv("NRLDPC_RR_GENERAL") != nullptr; // A/B: force the general kernel
-    for (int r = 0; r < a.C; ++r) repeats = repeats || a.E[r] > P;
+    static const bool force_general = getenv("NRLDPC_RR_GENERAL") != nullptr; // A/B: force the general kernel
+    // the input-driven form where it measured faster than the gather -- with the HARQ buffer and Q_m <= 2: -25 % on the headline code;
+    // it loses 6-17 % without the buffer, 21 % at 64QAM with it, and 2.4 x on kilobyte-sized blocks (profiles/r06_rate_recover_scatter_ab.txt).
+    // NRLDPC_RR_SCATTER=0 / 1 forces the gather / the scatter wherever it applies (A/B)
+    static const int env_scatter = getenv("NRLDPC_RR_SCATTER") ? atoi(getenv("NRLDPC_RR_SCATTER")) : -1;
+    bool repeats = force_general;
+    int emax = 0;
+    for (int r = 0; r < a.C; ++r) { repeats = repeats || a.E[r] > P; emax = a.E[r] > emax ? a.E[r] : emax; }
     const bool qm_ok = a.Qm == 1 || a.Qm == 2 || a.Qm == 4 || a.Qm == 6 || a.Qm == 8;
-    if (!repeats && qm_ok) {
+    const bool scatter = env_scatter >= 0 ? env_scatter != 0 : (a.harq != nullptr && a.Qm <= 2 && a.N >= 4096);
+    if (!repeats && qm_ok && scatter) {
+        if (a.out_f16) launch_rr_scatter<__half>(a, emax, stream);
+        else launch_rr_scatter<float>(a, emax, stream);
+    } else if (!repeats && qm_ok) {
         if (a.out_f16) launch_rr_fast<__half>(a, grid, stream);
         else launch_rr_fast<float>(a, grid, stream);
     } else if (a.out_f16) {

@@ -116,20 +116,53 @@ def mixed(B=8192, iters=25):
     return rec
 
 
+CFG3 = (("1/5", 19120, 42, -3.0), ("1/4", 15296, 32, -2.0), ("1/3", 11472, 22, -0.5), ("2/5", 9560, 17, 0.5),
+        ("1/2", 7648, 12, 2.0), ("3/5", 6374, 9, 3.2), ("2/3", 5736, 7, 4.5))
+
+
+def pruned_runs():
+    """The BASELINE configurations with a pruned layer count (cfg3's six rates above 1/5, cfg5), both modes each."""
+    out = []
+    for R, E, nl, esn0 in CFG3[1:]:
+        out.append(run("cfg3 BG2 Z=384 R=%s 25it fixed, batch 4096" % R, 2, 384, 4096, E, nl, 25, 0, esn0))
+        out.append(run("cfg3 BG2 Z=384 R=%s early stop, batch 4096" % R, 2, 384, 4096, E, nl, 25, 1, esn0))
+    out.append(run("cfg5 BG1 Z=384 R=8/9 early stop, 8192 codewords (one GPU's shard of 65536)", 1, 384, 8192, 9478, 5, 25, 1, 7.5))
+    out.append(run("cfg5 worst case: no early stop", 1, 384, 8192, 9478, 5, 25, 0, 7.5))
+    return out
+
+
 def main():
     out = []
     if "--only-mixed" in sys.argv:
         mixed()
         return
+    if "--rt-child" in sys.argv:  # started by the parent below with NRLDPC_NO_PRUNED_PIPELINE=1: the run-time-prefix builds (NL_RT) serve every pruned count
+        print("RT_CHILD_JSON " + json.dumps(pruned_runs()), flush=True)
+        return
     out.append(run("cfg2 BG1 Z=384 R=1/3 25it fixed, batch 4096 (headline)", 1, 384, 4096, 25344, 0, 25, 0, -0.5))
     out.append(run("cfg2 with parity-check early stop (reference semantics)", 1, 384, 4096, 25344, 0, 25, 1, -0.5))
-    for R, E, nl, esn0 in (("1/5", 19120, 42, -3.0), ("1/4", 15296, 32, -2.0), ("1/3", 11472, 22, -0.5), ("2/5", 9560, 17, 0.5),
-                           ("1/2", 7648, 12, 2.0), ("3/5", 6374, 9, 3.2), ("2/3", 5736, 7, 4.5)):
+    for R, E, nl, esn0 in CFG3:
         out.append(run("cfg3 BG2 Z=384 R=%s 25it fixed, batch 4096" % R, 2, 384, 4096, E, nl, 25, 0, esn0))
         out.append(run("cfg3 BG2 Z=384 R=%s early stop, batch 4096" % R, 2, 384, 4096, E, nl, 25, 1, esn0))
     out.append(mixed())
     out.append(run("cfg5 BG1 Z=384 R=8/9 early stop, 8192 codewords (one GPU's shard of 65536)", 1, 384, 8192, 9478, 5, 25, 1, 7.5))
     out.append(run("cfg5 worst case: no early stop", 1, 384, 8192, 9478, 5, 25, 0, 7.5))
+    # VERDICT r5 item 5: the pruned BASELINE configurations have compile-time-NL builds of their own (NRLDPC_Z64_NL_LIST); every OTHER
+    # (A, R) a caller picks runs the same kernels with the layer count as a run-time prefix (NL_RT).  Both, side by side: the
+    # second figure is what an arbitrary rate gets.  (The dispatch reads NRLDPC_NO_PRUNED_PIPELINE once per process: a child.)
+    import subprocess
+    env = dict(os.environ, NRLDPC_NO_PRUNED_PIPELINE="1")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--rt-child"], capture_output=True, text=True, env=env)
+    rt = {}
+    for line in p.stdout.splitlines():
+        if line.startswith("RT_CHILD_JSON "):
+            rt = {r["config"]: r for r in json.loads(line[len("RT_CHILD_JSON "):])}
+    for r in out:
+        q = rt.get(r.get("config"))
+        if q and r.get("n_layers") != DIMS[r["bg"]][0]:
+            r["run_time_prefix_build"] = {"kernel_ms": q["kernel_ms"], "info_Gbit_s": q["info_Gbit_s"], "mean_iters": q["mean_iters"],
+                                          "ratio_to_the_listed_build": q["kernel_ms"] / r["kernel_ms"]}
+            print({"config": r["config"], "listed_build_ms": r["kernel_ms"], "run_time_prefix_ms": q["kernel_ms"]}, flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs%s.json" % os.environ.get("OUT_SUFFIX", "")), "w"), indent=1)
 
