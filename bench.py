@@ -46,7 +46,7 @@ ALG_BYTES_PER_CW = ITERS * 4 * S_BYTES * NNZ * Z + N_CW * S_BYTES + K // 8  # 12
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2  # 256 CUs x 4 SIMDs, one wave64 VALU op per 2 cycles (MI355X_MICROARCH.md)
 # rocprofv3 summaries of this very command (tools/profile_gpu.sh + tools/summarise_profile.py); newest round first
-PROFILE_TAGS = ("r05", "r04", "r03", "r02", "r01")
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02", "r01")
 
 
 def _profile(kernel_id):

@@ -28,6 +28,10 @@
 #include "nrldpc_hostpath.h"
 #include "nrldpc_kernels.h"
 #include "nrldpc_host_quant.h"
+
+#ifndef NRLDPC_HOST_SPIN_US_DEFAULT
+#define NRLDPC_HOST_SPIN_US_DEFAULT 300 // see HostPool::spin_us
+#endif
 #include "nrldpc_sched.h"
 
 namespace {
@@ -193,13 +197,20 @@ class HostPool {
     std::atomic<int> sleepers_{0};
     std::atomic<bool> stop_{false};
 
-    // NRLDPC_HOST_SPIN_US: how long an idle copy thread polls for the next job before it sleeps.  Default 0: polling
-    // saves ~0.1 ms per job on an idle host, but a container with a CPU quota (the MI355X boxes of this build: 256 CPUs
-    // visible, cpu.max = 16) charges polling like work, and a throttled process loses 20-30 ms at a time.
+    // NRLDPC_HOST_SPIN_US: how long an idle copy thread polls for the next job before it sleeps -- WHILE A CALL IS IN FLIGHT
+    // (hot_: set by the chunked host path for its duration); between calls the threads sleep at once.  Waking fifteen sleeping
+    // threads costs 50-150 us per job, a chunked call is 11 jobs, and round 6 measured what that adds up to: the copy / quantise
+    // phase of a 4096-codeword call of doubles takes 4.4 ms with polling threads and 6.0-8.7 ms with sleeping ones (fp16: 1.0 against
+    // 2.0-3.0; profiles/r06_host_copy_thread_polling.txt) -- most of what rounds 4 and 5 read as "the host's DRAM drifts".
+    // Through round 5 the default was 0: a container with a CPU quota (the MI355X boxes of this build: 256 CPUs visible,
+    // cpu.max = 16) charges polling like work, and a throttled process loses 20-30 ms at a time.  Polling only inside a call and
+    // only for a bounded time after each job keeps that charge to the gaps between the jobs of a copy-bound call (tens of
+    // microseconds each); a device-bound call's long gaps still put the threads to sleep.
     static int spin_us() {
-        static const int v = getenv("NRLDPC_HOST_SPIN_US") ? atoi(getenv("NRLDPC_HOST_SPIN_US")) : 0;
+        static const int v = getenv("NRLDPC_HOST_SPIN_US") ? atoi(getenv("NRLDPC_HOST_SPIN_US")) : NRLDPC_HOST_SPIN_US_DEFAULT;
         return v;
     }
+    std::atomic<bool> hot_{false};
     static void relax() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -224,7 +235,8 @@ public:
                     int polls = 0;
                     while (gen_.load(std::memory_order_acquire) == seen && !stop_.load(std::memory_order_relaxed)) {
                         relax();
-                        if (((++polls & 255) == 0 || spin_us() == 0) && std::chrono::steady_clock::now() - t0 >= std::chrono::microseconds(spin_us())) {
+                        const bool hot = hot_.load(std::memory_order_relaxed);
+                        if (!hot || (((++polls & 255) == 0 || spin_us() == 0) && std::chrono::steady_clock::now() - t0 >= std::chrono::microseconds(spin_us()))) {
                             std::unique_lock<std::mutex> lk(m_);
                             sleepers_.fetch_add(1);
                             cv_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
@@ -249,6 +261,8 @@ public:
         cv_.notify_all();
         for (auto& t : th_) t.join();
     }
+    // a chunked call is in flight (the workers poll between its jobs) / over (they sleep)
+    void set_hot(bool on) { hot_.store(on, std::memory_order_relaxed); }
     // Run the workers on the NUMA node that holds the caller's array (no-op when it is unknown or unchanged).
     void follow(const void* p, size_t bytes) {
         if (nodes_.size() < 2) return;
@@ -1054,6 +1068,11 @@ int decode_host(nrldpc_handle h, const void* llr, int32_t batch, uint8_t* hard, 
             if (!h->pool) return fail(NRLDPC_ERR_NOMEM, "host thread pool");
         }
         h->pool->follow(llr, (size_t)batch * ncw * host_eb);
+        struct Hot { // the copy threads poll between the jobs of this call, and sleep again when it returns (whichever way)
+            HostPool* p;
+            explicit Hot(HostPool* q) : p(q) { p->set_hot(true); }
+            ~Hot() { p->set_hot(false); }
+        } hot_guard(h->pool);
         // NRLDPC_LAYERS_AUTO, on the copy threads (the all-zero column blocks are read here, once).  Chunk by chunk: the count is
         // taken from the FIRST chunk, and each later chunk's tail above it is checked right before that chunk is quantised -- the
         // device already works on the earlier chunks meanwhile, where a scan of the whole batch up front was a serial phase as long

@@ -61,6 +61,8 @@ template <> NRLDPC_T512 inline __m512 load16<NRLDPC_HQ_F64>(const void* src, siz
     const __m256 lo = _mm512_cvtpd_ps(_mm512_loadu_pd(d)), hi = _mm512_cvtpd_ps(_mm512_loadu_pd(d + 8));
     return _mm512_insertf32x8(_mm512_castps256_ps512(lo), hi, 1);
 }
+// (A software prefetch 1 KB / 4 KB ahead of the reads was measured in round 6, the paths alternated call by call on one array: within
+// +-2 % of this loop for doubles, fp16 and singles -- profiles/r06_host_copy_thread_polling.txt.  Not kept.)
 template <int KIND> NRLDPC_T512 bool quant_avx512(int8_t* dst, const void* src, size_t n, float scale) {
     const __m512 vs = _mm512_set1_ps(scale), lo = _mm512_set1_ps(-127.0f), hi = _mm512_set1_ps(127.0f), pinf = _mm512_set1_ps(__builtin_inff()),
                  ninf = _mm512_set1_ps(-__builtin_inff());

@@ -186,17 +186,17 @@ def test_count_layers_is_the_definition_of_auto(pkg):
 
 
 def test_committed_profile_belongs_to_the_tree_kernels(pkg):
-    """bench.py takes its VALU instruction counts and HBM traffic from profiles/r05_* only when their nrldpc_kernel_id equals
+    """bench.py takes its VALU instruction counts and HBM traffic from profiles/r06_* only when their nrldpc_kernel_id equals
     the loaded library's (a kernel change without a profile refresh silently falsified a fraction).  This test
     makes the refresh hard to forget: the committed summaries must be those of the decoder kernels in the tree."""
     import json
     kid = pkg._capi._build.kernel_id()
     assert pkg.load().nrldpc_kernel_id().decode() == kid
-    for f in ("r05_bench_pmc_summary.json", "r05_traffic_bytes_per_launch.json", "r05_headline_isa_mix.json"):
+    for f in ("r06_bench_pmc_summary.json", "r06_traffic_bytes_per_launch.json", "r06_headline_isa_mix.json"):
         d = json.load(open(os.path.join(ROOT, "profiles", f)))
         got = d.get("_nrldpc_kernel_id") or d.get("nrldpc_kernel_id")
         assert got == kid, "%s was measured on kernels %s, the tree holds %s: re-run tools/final_session.sh" % (f, got, kid)
-    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_line.json")))
     assert line["roofline"]["profile"]["nrldpc_kernel_id"] == kid and line["roofline"]["frac"] is not None
     assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] == "valu_issue"
 

@@ -1,8 +1,8 @@
 #!/bin/bash
-# The measurement set behind profiles/r05_*: GPU tests, bench line, every BASELINE configuration, all lifting sizes, chain stages
+# The measurement set behind profiles/r06_*: GPU tests, bench line, every BASELINE configuration, all lifting sizes, chain stages
 # (+ their kernel trace), Monte-Carlo loop, host path, rocprofv3 kernel trace + PMC passes of the bench command.
-# TAG=r05 bash tools/final_session.sh ; then on the build box: python tools/collect_profiles.py r05
-TAG=${TAG:-r05}
+# TAG=r06 bash tools/final_session.sh ; then on the build box: python tools/collect_profiles.py r06
+TAG=${TAG:-r06}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 if [ -z "$SKIP_TESTS" ]; then
