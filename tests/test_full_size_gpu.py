@@ -358,6 +358,32 @@ def test_bench_survives_an_rccl_that_does_not_come_up_and_has_a_one_process_rout
     assert rec["ms_per_step"] > 0 and rec["roofline"]["kernel_ms"] > 0
 
 
+def test_bench_over_a_probed_rccl_group_with_one_rank():
+    """The branch the driver's 8-GPU run takes when RCCL comes up: gloo default group, RCCL probed in a thread (second process group + one
+    all-reduce on the rank's GPU), then the barrier, the max-over-ranks and the per-GPU gathers over that group.  A one-GPU box cannot hold
+    two RCCL ranks, but it can hold ONE: BENCH_COMM_WORLD1=1 makes a single rank under the launcher go through the whole protocol, so every
+    torch.distributed call of that branch has run on the real backend before the first multi-GPU job does."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}, BENCH_COMM_WORLD1="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "512",
+           "--cpu-sample", "0", "--no-e2e", "--no-early-term", "--cfg5", "--cfg5-total", "1024", "--cfg5-steps", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 1.0 and rec["comm"]["requested"] == "nccl" and rec["comm"]["world_size"] == 1
+    assert rec["comm"]["backend"] == "nccl" and rec["comm"]["fallback"] is None and rec["comm"]["rccl_version"], rec["comm"]
+    assert rec["cfg5_strong"]["per_gpu"][0]["codewords"] == 1024 and len(rec["roofline"]["per_gpu"]) == 1
+
+
 def test_cfg5_full_batch_65536_through_eight_shards(pkg, orc):
     """BASELINE configs[4] at its full size: 65536 BG1 Z=384 R=8/9 codewords with early termination, cut over EIGHT
     shards (the pool dispatcher with eight handles and host threads; on this one-GPU box all eight sit on device 0).
