@@ -417,6 +417,9 @@ class Comm:
         torch, dist = self.torch, self.dist
         if not use_gpu or not torch.cuda.is_available():
             return False, "no HIP device in this process"
+        # a collective that times out must come back to THIS code as an error (or not at all: the join below has its own limit), not as
+        # the watchdog's default reaction -- tearing the whole process down -- or the fall back could never run
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
         res = {}
 
         def run():
