@@ -105,6 +105,12 @@ class DeviceDecodeChain:
                 raise NRLDPCError("batch size changed from %d to %d transport blocks with HARQ state pending "
                                   "(I_HARQ ~= 0); call reset() first." % (self.cb_pass.shape[0], n_tb))
             self.cb_pass = self.b_hat = self.harq = None
+        if self.cb_pass is not None and (self.cb_pass.shape[1] != C_ or self.b_hat.shape[1] != d.B or
+                                         (self.harq is not None and self.harq.shape[2] != d.N_cb)):
+            # another code on the same parameter object (A changed between steps): buffers of the old one's sizes hold nothing that
+            # belongs to these transport blocks -- a new set, as after reset() (the codec itself: _codec_for)
+            self.cb_pass = self.b_hat = self.harq = None
+            self._layers_seen = 4
         if self.cb_pass is None:
             self.cb_pass = torch.zeros((n_tb, C_), dtype=torch.int32, device=self.dev)
             self.b_hat = torch.zeros((n_tb, d.B), dtype=torch.uint8, device=self.dev)

@@ -125,6 +125,33 @@ def test_device_encode_chain_equals_host_chain(pkg, kw):
     enc.release()
 
 
+def test_device_chains_follow_a_changed_code(pkg):
+    """a plain NRLDPC parameter object is not locked, so A (and with it Z_c, K) may change between the steps of a device chain.
+    The chains keep ONE codec; built for the old (BG, Z_c) it would read and write tensors sized for the new code out of bounds.  They
+    now rebuild it when the pair changes: the same chain objects, three payload sizes in a row, each a noise-free round trip, and the
+    transmit side equal to the host mirror's."""
+    import torch
+    DC = importlib.import_module("ldpc-3gpp-matlab_amd.device_chain")
+    rng = np.random.default_rng(5)
+    p = pkg.NRLDPC(BG=2, A=200, G=900, Q_m=2)
+    tx, rx = DC.DeviceEncodeChain(p), DC.DeviceDecodeChain(p, iterations=10, llr_dtype=np.float32)
+    seen = set()
+    for A, G in ((200, 900), (1000, 4000), (3000, 9600), (200, 900)):
+        p.A, p.G = A, G
+        p.validate()
+        seen.add(p.Z_c)
+        a = rng.integers(0, 2, (3, A), dtype=np.uint8)
+        g = tx.step(torch.from_numpy(a).cuda())
+        enc = pkg.NRLDPCEncoder(BG=2, A=A, G=G, Q_m=2)
+        assert (g.cpu().numpy() == enc.step_batch(a)).all(), (A, G)
+        enc.release()
+        a_hat, ok, _ = rx.step((1.0 - 2.0 * g.float()) * 6.0)
+        torch.cuda.synchronize()
+        assert bool(ok.all()) and (a_hat.cpu().numpy() == a).all(), (A, G)
+    assert len(seen) == 3  # three lifting sizes through one pair of chain objects
+    tx.close(); rx.close()
+
+
 def test_torch_modulation_matches_numpy(pkg):
     import torch
     H = importlib.import_module("ldpc-3gpp-matlab_amd.harness")
