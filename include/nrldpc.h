@@ -61,7 +61,8 @@ typedef struct nrldpc_codec* nrldpc_handle;
  * layers" below; and adds nrldpc_pool_decode_packed.  nrldpc_cfg and nrldpc_dims keep their revision-4 layout and size.
  * Revision 6 adds nrldpc_decode_packed_layers (the layer count as an ARGUMENT of one call: nothing sticks to the handle) and
  * nrldpc_pool_set_timing / nrldpc_pool_last_kernel_ms (event-pair kernel times of every shard of a pool) and
- * nrldpc_last_host_phases (the phase times of a large host-pointer call); nothing a revision-5 caller uses changed meaning. */
+ * nrldpc_last_host_phases (the phase times of a large host-pointer call) and nrldpc_payload_bits_dev (the Monte-Carlo loop's payload
+ * draw as one kernel); nothing a revision-5 caller uses changed meaning. */
 #define NRLDPC_ABI_VERSION 6
 
 /* Active layers.  The reference always decodes the full H (NRLDPCDecoder.m:120).  A base-graph row i >= 4 owns the degree-1
@@ -285,6 +286,12 @@ int nrldpc_rate_match_dev(const nrldpc_tb_params* p, const uint8_t* d_cw, int32_
  * the same (seed, symbol) always sees the same noise, whatever the batch split.  Current HIP device. */
 int nrldpc_awgn_llr_dev(const uint8_t* d_g, int64_t n_bits, int32_t Q_m, float EsN0_dB, uint64_t seed,
                         uint64_t first_symbol, float* d_g_tilde, void* stream);
+/* Payload of the Monte-Carlo loop: replaces `a = round(rand(A,1))` of plot_BLER_vs_SNR.m:118 for n_tb transport blocks at once.
+ * d_a: [n_tb][A] bytes {0,1}; bit i of the block with GLOBAL index first_block + b is bit (i mod 64) of
+ * splitmix64(seed + ((first_block + b) * ceil(A/64) + i div 64 + 1) * 0x9E3779B97F4A7C15) -- the same (seed, block) always draws the
+ * same payload, whatever the batch split (MATLAB's Mersenne-Twister stream cannot be replicated outside MATLAB: SURVEY.md 8c; curves
+ * are compared statistically).  Current HIP device.  (ABI revision 6.) */
+int nrldpc_payload_bits_dev(uint64_t seed, uint64_t first_block, int32_t n_tb, int32_t A, uint8_t* d_a, void* stream);
 
 /* Kernel timing: when enabled, every *_dev / host call records HIP events around its kernel on the
  * launch stream; nrldpc_last_kernel_ms synchronises on the stop event and returns the duration. */

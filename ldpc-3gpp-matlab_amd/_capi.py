@@ -76,7 +76,7 @@ EXPORTS = ["nrldpc_awgn_llr_dev", "nrldpc_rate_recover_dev",  "nrldpc_crc_check_
            "nrldpc_version", "nrldpc_build_id", "nrldpc_kernel_id", "nrldpc_pool_create", "nrldpc_pool_decode", "nrldpc_pool_last_split",
            "nrldpc_pool_destroy", "nrldpc_pool_decode_dev", "nrldpc_pool_size", "nrldpc_abi_version", "nrldpc_decode_packed",
            "nrldpc_set_layers", "nrldpc_set_llr_dtype", "nrldpc_last_layers", "nrldpc_count_layers", "nrldpc_pool_set_layers", "nrldpc_pool_decode_packed",
-           "nrldpc_decode_packed_layers", "nrldpc_pool_set_timing", "nrldpc_pool_last_kernel_ms", "nrldpc_last_host_phases"]
+           "nrldpc_decode_packed_layers", "nrldpc_pool_set_timing", "nrldpc_pool_last_kernel_ms", "nrldpc_last_host_phases", "nrldpc_payload_bits_dev"]
 
 _lib = None
 
@@ -133,6 +133,7 @@ def load():
     L.nrldpc_decode_packed_layers.argtypes = [vp, vp, i32, vp, vp, i32]
     L.nrldpc_pool_set_timing.argtypes = [vp, i32]
     L.nrldpc_last_host_phases.argtypes = [vp, C.POINTER(C.c_double)]
+    L.nrldpc_payload_bits_dev.argtypes = [C.c_uint64, C.c_uint64, i32, i32, vp, vp]
     L.nrldpc_pool_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nrldpc_decode_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.nrldpc_quantise_llr.argtypes = [vp, vp, C.c_int64, i32, i32]
@@ -463,6 +464,11 @@ def awgn_llr_dev(d_g, n_bits, Q_m, EsN0_dB, seed, first_symbol, d_g_tilde, strea
     """nrldpc_awgn_llr_dev: modulation + AWGN + exact LLRs in one kernel (plot_BLER_vs_SNR.m:130-132)."""
     check(load().nrldpc_awgn_llr_dev(_ptr(d_g), int(n_bits), int(Q_m), float(EsN0_dB), int(seed), int(first_symbol),
                                      _ptr(d_g_tilde), C.c_void_p(stream)))
+
+
+def payload_bits_dev(seed, first_block, n_tb, A, d_a, stream=0):
+    """nrldpc_payload_bits_dev: the Monte-Carlo loop's payload draw (plot_BLER_vs_SNR.m:118) for n_tb blocks in one kernel."""
+    check(load().nrldpc_payload_bits_dev(int(seed) % (1 << 64), int(first_block), int(n_tb), int(A), _ptr(d_a), C.c_void_p(stream)))
 
 
 def crc_attach_dev(p, d_a, n_tb, d_c, stream=0):

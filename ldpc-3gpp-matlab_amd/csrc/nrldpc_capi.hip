@@ -1794,6 +1794,21 @@ int nrldpc_awgn_llr_dev(const uint8_t* d_g, int64_t n_bits, int32_t Q_m, float E
     return NRLDPC_OK;
 }
 
+} // extern "C"
+namespace nrldpc { // nrldpc_channel.hip (declared here, not in nrldpc_kernels.h: that header is part of the decoder kernels' identity, nrldpc_kernel_id)
+hipError_t launch_payload_bits(uint64_t seed, uint64_t first_block, int32_t n_tb, int32_t A, uint8_t* out, hipStream_t stream);
+}
+extern "C" {
+
+int nrldpc_payload_bits_dev(uint64_t seed, uint64_t first_block, int32_t n_tb, int32_t A, uint8_t* d_a, void* stream) {
+    if (n_tb < 0 || A < 1) return fail(NRLDPC_ERR_ARG, "n_tb must be non-negative and A positive");
+    if (n_tb == 0) return NRLDPC_OK;
+    if (!d_a) return fail(NRLDPC_ERR_ARG, "null pointer");
+    hipError_t e = nrldpc::launch_payload_bits(seed, first_block, n_tb, A, d_a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hipfail(e, "payload kernel launch");
+    return NRLDPC_OK;
+}
+
 int nrldpc_encode_dev(nrldpc_handle h, const uint8_t* d_info, int32_t batch, uint8_t* d_cw, void* stream) {
     if (!h) return fail(NRLDPC_ERR_ARG, "null handle");
     if (batch < 0) return fail(NRLDPC_ERR_ARG, "negative batch");

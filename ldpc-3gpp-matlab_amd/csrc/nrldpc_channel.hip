@@ -139,6 +139,37 @@ template <int QM> __global__ __launch_bounds__(256) void nrldpc_awgn_llr_kernel(
     }
 }
 
+// ---- payload bits of the Monte-Carlo loop (plot_BLER_vs_SNR.m:118: a = round(rand(A,1)) per block) ---------------------------------
+// Bit i of transport block b = bit (i mod 64) of splitmix64(seed + (b*W + i div 64 + 1) * golden), W = ceil(A/64): a function of the
+// GLOBAL block index alone (harness.payload_bits_np is the definition), so any split of a batch over devices draws the same payloads.
+// One kernel instead of the fifteen small tensor operations the harness made of it (round 6: a fifth of a demo-sized step).
+// A thread writes four consecutive bits of a block as four bytes (64 % 4 == 0: they never straddle a hash word).
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void nrldpc_payload_bits_kernel(uint64_t seed, uint64_t first_block, int32_t n_tb, int32_t A, uint8_t* out) {
+    const int q4 = (A + 3) >> 2; // four-bit chunks per block
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)n_tb * q4) return;
+    const int b = (int)(t / q4), c = (int)(t - (int64_t)b * q4);
+    const int i0 = 4 * c, W = (A + 63) >> 6;
+    const uint64_t h = splitmix64(seed + (((first_block + (uint64_t)b) * (uint64_t)W + (uint64_t)(i0 >> 6)) + 1ull) * 0x9E3779B97F4A7C15ull);
+    const uint32_t nib = (uint32_t)(h >> (i0 & 63)) & 0xFu;
+    uint8_t* o = out + (size_t)b * A + i0;
+    if (i0 + 4 <= A && (reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+        *reinterpret_cast<uint32_t*>(o) = (nib * 0x00204081u) & 0x01010101u; // bit k of the nibble -> byte k
+    } else {
+        for (int k = 0; k < 4 && i0 + k < A; ++k) o[k] = (uint8_t)((nib >> k) & 1u);
+    }
+}
+hipError_t launch_payload_bits(uint64_t seed, uint64_t first_block, int32_t n_tb, int32_t A, uint8_t* out, hipStream_t stream) {
+    const int64_t n = (int64_t)n_tb * ((A + 3) >> 2);
+    hipLaunchKernelGGL(nrldpc_payload_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, seed, first_block, n_tb, A, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_awgn_llr(const ChanArgs& a, hipStream_t stream) {
     // pairs of the global symbol count that the launch touches
     const uint64_t npairs = ((a.first_symbol + (uint64_t)a.n_sym - 1) >> 1) - (a.first_symbol >> 1) + 1;

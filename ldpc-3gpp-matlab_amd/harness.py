@@ -134,21 +134,15 @@ def payload_bits_np(seed, first_block, n, A):
 
 
 def payload_bits(seed, first_block, n, A, dev):
-    """The same on the device: one hash per 64 payload bits (int64 arithmetic wraps like uint64; right shifts made logical
-    by masking), bits unpacked from the little-endian byte view."""
+    """The same on the device: one kernel of the library (nrldpc_payload_bits_dev; through round 5 fifteen small tensor operations,
+    a fifth of a demo-sized step of the loop)."""
     import torch
-    s64 = lambda c: c - (1 << 64) if c >= (1 << 63) else c
-    lsr = lambda x, k: (x >> k) & ((1 << (64 - k)) - 1)
-    W = (A + 63) // 64
-    idx = (torch.arange(first_block, first_block + n, device=dev, dtype=torch.int64)[:, None] * W
-           + torch.arange(W, device=dev, dtype=torch.int64)[None, :])
-    x = (idx + 1) * s64(_SM64[0]) + s64(seed % (1 << 64))
-    x = (x ^ lsr(x, 30)) * s64(_SM64[1])
-    x = (x ^ lsr(x, 27)) * s64(_SM64[2])
-    x = x ^ lsr(x, 31)
-    by = x.contiguous().view(torch.uint8).reshape(n, W * 8, 1)                     # little-endian bytes of every word
-    bits = (by >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1
-    return bits.reshape(n, W * 64)[:, :A].contiguous()
+    from ._capi import payload_bits_dev
+    out = torch.empty((n, A), dtype=torch.uint8, device=dev)
+    if n:
+        with torch.cuda.device(dev):
+            payload_bits_dev(seed, first_block, n, A, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    return out
 
 
 ATTEMPT_STRIDE = 1 << 40  # Philox symbol counter = attempt * 2^40 + global block index * symbols per block + symbol
