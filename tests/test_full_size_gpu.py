@@ -248,6 +248,43 @@ def test_pool_of_logical_shards_equals_one_launch(pkg, orc):
         pkg.CodecPool(bg, Z, [0, 99])                         # a device that does not exist: the whole pool fails
 
 
+def test_abi_revision_6_through_the_python_binding(pkg, orc):
+    """What ABI revision 6 added, through ldpc-3gpp-matlab_amd/_capi.py (tests/abi_caller covers the C side): the layer count as an argument
+    of ONE call (nothing sticks to the handle), the phase times of a chunked host-pointer call, per-shard kernel times of a pool."""
+    rng = np.random.default_rng(66)
+    bg, Z, B, act = 1, 384, 1200, 9
+    c = pkg.Codec(bg, Z, max_iter=12, n_layers=0, early_term=True, llr_dtype=np.float32)
+    info = rng.integers(0, 2, (B, c.K), dtype=np.uint8)
+    llr = awgn_llr(rng, c.encode(info), 7.5, np.float32, Z, E=(22 + act - 2) * Z)  # nothing transmitted above `act` rows
+    assert c.last_host_phases() is None                                   # no chunked call yet
+    full, it_full = c.decode_packed(llr, want_iters=True)                 # the handle's own setting: every row
+    assert c.last_layers() == 46
+    ph = c.last_host_phases()
+    assert ph is not None and ph["chunks"] >= 1 and ph["layers"] == 46 and ph["copy_quantise_ms"] > 0 and ph["copy_out_ms"] >= 0
+    per_call, it_call = c.decode_packed(llr, want_iters=True, n_layers=act)
+    assert c.last_layers() == act and c.last_host_phases()["layers"] == act
+    again = c.decode_packed(llr)                                          # ... and the next call without a count: every row again
+    assert c.last_layers() == 46 and (again == full).all()
+    c.set_layers(act)
+    sticky, it_sticky = c.decode_packed(llr, want_iters=True)
+    assert (sticky == per_call).all() and (it_sticky == it_call).all()    # the per-call count == nrldpc_set_layers(act)
+    auto = c.decode_packed(llr, n_layers=pkg._capi.LAYERS_AUTO)
+    assert c.last_layers() == act and (auto == per_call).all()
+    with pytest.raises(pkg.UnsupportedParameters):
+        c.decode_packed(llr, n_layers=3)
+    c.close()
+    bits = np.unpackbits(per_call, axis=1, bitorder="little")[:, : 22 * Z]
+    assert (bits == info).mean() > 0.999
+    pool = pkg.CodecPool(bg, Z, [0, 0], chunks_per_device=2, max_iter=12, n_layers=act, early_term=True, llr_dtype=np.float32)
+    with pytest.raises(pkg.NRLDPCError):
+        pool.last_kernel_ms()                                             # timing not enabled
+    pool.set_timing(True)
+    h = pool.decode(llr)
+    ms = pool.last_kernel_ms()
+    assert len(ms) == 2 and all(m >= 0 for m in ms) and sum(ms) > 0 and (np.packbits(h, axis=1, bitorder="little") == per_call).all()
+    pool.close()
+
+
 def test_pool_decode_dev_shards_device_resident_batches(pkg, orc):
     """nrldpc_pool_decode_dev: per-shard DEVICE pointers -- data that is already on the GPUs goes
     through the pool without touching the host; one launching thread and stream per shard.  Three logical shards on this
