@@ -221,10 +221,12 @@ def _count_outcomes(outcomes, found_start, errors, blocks, BLER, target_block_er
 
 
 def _num2str(x):
-    """MATLAB num2str for the values used in the result file name (4 significant decimals, %g-like)."""
+    """MATLAB num2str for the values used in the result file names: integers plainly, otherwise
+    %.<d>g with d = max(1, floor(log10|x|) + 1) + 4 significant digits ('0.33333', '0.01', '0.001', '1234.5')."""
     if float(x) == int(x):
         return str(int(x))
-    return ("%.5g" % x)
+    d = max(1, int(np.floor(np.log10(abs(float(x))))) + 1) + 4
+    return "%.*g" % (d, x)
 
 
 def simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng):
@@ -320,3 +322,96 @@ def plot_BLER_vs_SNR(A=3842, R=1 / 3, BG=2, Modulation="QPSK", rv_id_sequence=(0
                     continue
                 curves[(a_len, float(r), bg)] = points
     return curves
+
+
+def plot_SNR_vs_A(A=tuple(range(1000, 9000, 1000)), R=1 / 3, BG=1, Modulation="QPSK", rv_id_sequence=(0,), iterations=50,
+                  target_block_errors=100, target_BLER=1e-2, EsN0_start=-2.0, EsN0_delta=0.1, seed=0,
+                  results_dir="results", batch=256, max_points=400, decoder_kwargs=None, device=False, devices=None,
+                  simulate=None):
+    """The reference's second harness, plot_SNR_vs_A.m:1-194 (same positional parameters and defaults, :38-48; no figure): for every
+    coding rate R and information block length A, the Es/N0 at which the BLER crosses target_BLER -- the SNR is stepped up from
+    EsN0_start in EsN0_delta steps (:103-108), target_block_errors errors are collected per SNR with the same found_start rule as
+    plot_BLER_vs_SNR (:145-161), and the crossing is interpolated between the last two SNRs in the log10-BLER domain (:175).  One
+    result file per rate, `results/SNR_vs_A_<target_BLER>_<R>_<BG>_<Mod>_<iters>_<errs>_<seed>.txt` (:80), one `%d\t%f` line per A
+    (:186); parameter sets the objects refuse are skipped (:165-172).  Blocks are simulated in batches, on the host mirror or with
+    every stage on the GPU(s) (device=True), exactly as in plot_BLER_vs_SNR.
+    simulate: test hook -- a function (A, EsN0, n, first_block) -> per-block outcomes that replaces the simulation.
+    Returns {R: [(A, EsN0 or nan), ...]}."""
+    rng = np.random.default_rng(seed)                                # :51
+    Q_m = Q_M.get(Modulation)
+    if Q_m is None:
+        raise UnsupportedParameters("Unsupported modulation")
+    A_list, R_list = [int(a) for a in np.atleast_1d(A)], [float(r) for r in np.atleast_1d(R)]
+    os.makedirs(results_dir, exist_ok=True)
+    out = {}
+    for r in R_list:                                                 # :69
+        name = "SNR_vs_A_%s_%s_%s_%s_%s_%s_%s.txt" % (_num2str(target_BLER), _num2str(r), _num2str(BG), Modulation,
+                                                      _num2str(iterations), _num2str(target_block_errors), _num2str(seed))  # :80
+        rows = []
+        with open(os.path.join(results_dir, name), "w") as fid:
+            for a_len in A_list:                                     # :88
+                found_start = False                                  # :90
+                chains = hEnc = hDec = None
+                try:
+                    BLER, prev_BLER = 1.0, float("nan")              # :95-96
+                    EsN0 = float(EsN0_start) - float(EsN0_delta)     # :97
+                    prev_EsN0 = EsN0
+                    G = int(round(a_len / r / Q_m) * Q_m)            # :98
+                    if simulate is None:
+                        hEnc = NRLDPCEncoder(A=a_len, BG=int(BG), G=G, Q_m=Q_m)                                   # :101
+                        hDec = NRLDPCDecoder(A=a_len, BG=int(BG), G=G, Q_m=Q_m, I_HARQ=1, iterations=iterations,
+                                             **(decoder_kwargs or {}))                                            # :102
+                        hEnc.validate()
+                        if device:
+                            from .device_chain import DeviceDecodeChain, DeviceEncodeChain
+                            from .nrldpc import NRLDPC
+                            chains = []
+                            for ordinal in (devices or [0]):
+                                shared = NRLDPC(A=a_len, BG=int(BG), G=G, Q_m=Q_m)
+                                chains.append((DeviceEncodeChain(shared, device_id=int(ordinal)),
+                                               DeviceDecodeChain(shared, iterations=iterations, I_HARQ=1, device_id=int(ordinal),
+                                                                 **(decoder_kwargs or {}))))
+                    curve_seed = (int(seed) * 0x9E3779B97F4A7C15 + a_len) % (1 << 64)  # payload / noise streams of this (seed, A)
+                    first_block, n_points = 0, 0
+                    while BLER > target_BLER and n_points < max_points:                 # :105
+                        prev_EsN0 = EsN0                                                 # :106
+                        EsN0 = EsN0 + float(EsN0_delta)                                  # :107
+                        blocks = errors = 0                                              # :114-115
+                        keep_going = True
+                        bler_now = 1.0
+                        while keep_going and errors < target_block_errors:               # :120
+                            if simulate is not None:
+                                outcomes = simulate(a_len, EsN0, batch, first_block)
+                            elif device:
+                                outcomes = simulate_point_device(chains, Q_m, EsN0, rv_id_sequence, batch, curve_seed, first_block)
+                            else:
+                                outcomes = simulate_point(hEnc, hDec, Q_m, EsN0, rv_id_sequence, batch, rng)
+                            first_block += batch
+                            found_start, keep_going, errors, blocks, bler_now = _count_outcomes(
+                                outcomes, found_start, errors, blocks, bler_now, target_block_errors)
+                        prev_BLER = BLER                                                 # :162
+                        BLER = bler_now                                                  # :163 (block_error_count / block_count; 1 / 1 before the first success)
+                        n_points += 1
+                except UnsupportedParameters:                        # :165-172: skip this (A, R)
+                    continue
+                finally:
+                    if hEnc is not None:
+                        hEnc.release()
+                    if hDec is not None:
+                        hDec.release()
+                    for tx_chain, rx_chain in (chains or []):
+                        tx_chain.close()
+                        rx_chain.close()
+                # :175 interp1(log10([prev_BLER, BLER]), [prev_EsN0, EsN0], log10(target_BLER)).  prev_BLER is 1 at EsN0_start -
+                # EsN0_delta when the first SNR already meets the target (:95-97,162); NaN, as interp1 gives out of range, when the
+                # sweep was cut by max_points before the target was met
+                x0, x1, xt = np.log10(prev_BLER) if prev_BLER == prev_BLER else float("nan"), np.log10(BLER), np.log10(target_BLER)
+                if x0 != x0 or x0 == x1 or not (min(x0, x1) <= xt <= max(x0, x1)):
+                    es = float("nan")
+                else:
+                    es = prev_EsN0 + (EsN0 - prev_EsN0) * (xt - x0) / (x1 - x0)
+                fid.write("%d\t%s\n" % (a_len, "NaN" if es != es else "%f" % es))      # :186
+                fid.flush()
+                rows.append((a_len, es))
+        out[r] = rows
+    return out

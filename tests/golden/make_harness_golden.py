@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/harness_golden.json: the result files plot_BLER_vs_SNR writes (plot_BLER_vs_SNR.m:79,165:
-one '%f\\t%e' line per finished Es/N0 point) for small seeded runs of the host harness.
+one '%f\\t%e' line per finished Es/N0 point) and those plot_SNR_vs_A writes (plot_SNR_vs_A.m:80,186: one '%d\\t%f'
+line per information block length) for small seeded runs of the host harness.
 
 The harness draws payloads and noise from numpy's PCG64 (stable across numpy versions) and the decoder core is
 bit-exact between the HIP kernels and the CPU oracle, so the whole Monte-Carlo run -- which SNR points exist, how many
@@ -32,6 +33,14 @@ RUNS = [  # keyword arguments of plot_BLER_vs_SNR (plot_BLER_vs_SNR.m:1,30-42)
          target_BLER=2e-2, EsN0_start=-1.0, EsN0_delta=0.5, seed=11, batch=64),
     dict(A=[40, 300], R=0.5, BG=2, Modulation="16QAM", rv_id_sequence=[0, 2], iterations=8, target_block_errors=15,
          target_BLER=1e-1, EsN0_start=2.0, EsN0_delta=0.5, seed=3, batch=32),
+]
+
+
+RUNS_SNR_VS_A = [  # keyword arguments of plot_SNR_vs_A (plot_SNR_vs_A.m:1,38-48)
+    dict(A=[40, 100, 300], R=[0.5, 1 / 3], BG=2, Modulation="QPSK", rv_id_sequence=[0], iterations=8, target_block_errors=12,
+         target_BLER=1e-1, EsN0_start=-2.0, EsN0_delta=0.5, seed=5, batch=24),
+    dict(A=[-1, 200], R=0.75, BG=2, Modulation="16QAM", rv_id_sequence=[0, 3], iterations=6, target_block_errors=10,
+         target_BLER=2e-1, EsN0_start=4.0, EsN0_delta=1.0, seed=2, batch=16),  # A=-1 is refused by the objects: skipped (:165-172)
 ]
 
 
@@ -78,6 +87,10 @@ def run_all(enc_factory=None, dec_factory=None):
             with tempfile.TemporaryDirectory() as d:
                 H.plot_BLER_vs_SNR(results_dir=d, **kw)
                 out[str(i)] = {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d))}
+        for i, kw in enumerate(RUNS_SNR_VS_A):
+            with tempfile.TemporaryDirectory() as d:
+                H.plot_SNR_vs_A(results_dir=d, **kw)
+                out["snr_vs_a_%d" % i] = {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d))}
         return out
     finally:
         H.NRLDPCEncoder, H.NRLDPCDecoder = saved

@@ -12,11 +12,20 @@ def test_fixture_is_what_the_oracle_backed_harness_gives(pkg, orc):
     import make_harness_golden as M
     want = json.load(open(os.path.join(GOLD, "harness_golden.json")))
     assert M.run_all(M.oracle_encoder, M.oracle_decoder) == want
-    for files in want.values():            # reference line format '%f\t%e' (plot_BLER_vs_SNR.m:165), BLER < 1 only (:164)
-        for txt in files.values():
+    for key, files in want.items():
+        for name, txt in files.items():
             for ln in txt.splitlines():
                 e, b = ln.split("\t")
-                assert len(e.split(".")[1]) == 6 and "e" in b and 0.0 < float(b) < 1.0
+                if key.startswith("snr_vs_a"):  # '%d\t%f' (plot_SNR_vs_A.m:186), file name of :80
+                    assert name.startswith("SNR_vs_A_") and e == str(int(e)) and len(b.split(".")[1]) == 6 and -5.0 < float(b) < 10.0
+                else:                           # '%f\t%e' (plot_BLER_vs_SNR.m:165), BLER < 1 only (:164)
+                    assert len(e.split(".")[1]) == 6 and "e" in b and 0.0 < float(b) < 1.0
+    # the refused information block length of the second plot_SNR_vs_A run left no line (plot_SNR_vs_A.m:165-172)
+    assert [ln.split("\t")[0] for ln in want["snr_vs_a_1"]["SNR_vs_A_0.2_0.75_2_16QAM_6_10_2.txt"].splitlines()] == ["200"]
+    # required SNR falls with the block length and with the rate, as in the reference's figure
+    for name, txt in want["snr_vs_a_0"].items():
+        snr = [float(ln.split("\t")[1]) for ln in txt.splitlines()]
+        assert snr == sorted(snr, reverse=True) and len(snr) == 3
 
 
 def _count_outcomes_loop(outcomes, found_start, errors, blocks, BLER, target_block_errors):
@@ -54,3 +63,83 @@ def test_outcome_bookkeeping_is_the_reference_loop(pkg):
             a = _count_outcomes_loop(list(ok), a[0], a[2], a[3], a[4], target)
             b = H._count_outcomes(ok, b[0], b[2], b[3], b[4], target)
             assert a == b, (trial, a, b)
+
+
+def _snr_vs_a_loop(A, R, Q_m, target_block_errors, target_BLER, EsN0_start, EsN0_delta, block_ok):
+    """plot_SNR_vs_A.m:88-186 for one rate, block by block, as the reference writes it (block_ok(A, EsN0, index) replaces :122-143)."""
+    import numpy as np
+    lines = []
+    for a_len in A:                                                           # :88
+        found_start = False                                                   # :90
+        BLER, prev_BLER = 1.0, float("nan")                                   # :95-96
+        EsN0 = EsN0_start - EsN0_delta                                        # :97
+        index = 0
+        while BLER > target_BLER:                                             # :105
+            prev_EsN0 = EsN0                                                  # :106
+            EsN0 = EsN0 + EsN0_delta                                          # :107
+            block_error_count = block_count = 0                               # :114-115
+            keep_going = True                                                 # :117
+            while keep_going and block_error_count < target_block_errors:     # :120
+                good = block_ok(a_len, EsN0, index)
+                index += 1
+                if not found_start and not good:                              # :145-149
+                    keep_going = False
+                    block_error_count = block_count = 1
+                else:
+                    found_start = True                                        # :151
+                    block_error_count += int(not good)                        # :154-156
+                    block_count += 1                                          # :160
+            prev_BLER = BLER                                                  # :162
+            BLER = block_error_count / block_count                            # :163
+        if prev_BLER != prev_BLER:
+            es = float("nan")
+        else:                                                                 # :175 interp1 over two points
+            x = np.log10([prev_BLER, BLER])
+            es = float(np.interp(np.log10(target_BLER), x[::-1], [EsN0, prev_EsN0])) if x[1] < x[0] else float("nan")
+        lines.append("%d\t%s\n" % (a_len, "NaN" if es != es else "%f" % es))  # :186
+    return "".join(lines)
+
+
+def test_snr_vs_a_is_the_reference_loop(pkg, tmp_path):
+    """harness.plot_SNR_vs_A against plot_SNR_vs_A.m's nested loops written out block by block, over a synthetic channel whose
+    block outcome is a function of (A, Es/N0, block index): with one block per batch the two must write the same file; with
+    whole batches (where the blocks after the error target are dropped) the crossing moves by less than a step."""
+    import importlib
+
+    import numpy as np
+    H = importlib.import_module("ldpc-3gpp-matlab_amd.harness")
+
+    def p_bad(a_len, EsN0):
+        return min(1.0, 10.0 ** (-(EsN0 - (-1.5 - 1e-4 * a_len)) * 2.5))
+
+    def block_ok(a_len, EsN0, index):
+        u = np.random.default_rng([a_len, index]).random()
+        return u >= p_bad(a_len, EsN0)
+
+    def simulate(a_len, EsN0, n, first_block):
+        return np.array([block_ok(a_len, EsN0, first_block + i) for i in range(n)])
+
+    kw = dict(A=[1000, 3000, 8000], R=1 / 3, BG=1, target_block_errors=15, target_BLER=3e-2, EsN0_start=-2.0, EsN0_delta=0.25, seed=4)
+    want = _snr_vs_a_loop(kw["A"], kw["R"], 2, 15, 3e-2, -2.0, 0.25, block_ok)
+    got = H.plot_SNR_vs_A(results_dir=str(tmp_path / "one"), batch=1, simulate=simulate, **kw)
+    (f,) = list((tmp_path / "one").iterdir())
+    assert f.name == "SNR_vs_A_0.03_0.33333_1_QPSK_50_15_4.txt"                  # :80 (iterations keeps its default of 50)
+    assert f.read_text() == want and len(want.splitlines()) == 3
+    assert [a for a, _ in got[1 / 3]] == kw["A"] and all(np.isfinite(e) for _, e in got[1 / 3])
+    batched = H.plot_SNR_vs_A(results_dir=str(tmp_path / "many"), batch=50, simulate=simulate, **kw)
+    for (_, e1), (_, e2) in zip(got[1 / 3], batched[1 / 3]):
+        assert abs(e1 - e2) < 0.25
+    # analytic crossing of the synthetic channel: p_bad = target  <=>  EsN0 = s0 - log10(target) / 2.5
+    for a_len, e in batched[1 / 3]:
+        assert abs(e - (-1.5 - 1e-4 * a_len - np.log10(3e-2) / 2.5)) < 0.2
+    # the first SNR already meets the target: the crossing is interpolated from (EsN0_start - EsN0_delta, BLER = 1), the values
+    # prev_EsN0 / prev_BLER hold then (:95-97,106,162); a sweep cut short of the target leaves NaN, as interp1 does out of range
+    first = H.plot_SNR_vs_A(A=[1000], EsN0_start=5.0, target_block_errors=3, target_BLER=0.5, results_dir=str(tmp_path / "first"),
+                            batch=8, simulate=lambda a, e, n, f: np.arange(f, f + n) % 4 != 1)
+    assert abs(first[1 / 3][0][1] - (4.9 + 0.1 * np.log10(0.5) / np.log10(0.3))) < 1e-9
+    cut = H.plot_SNR_vs_A(A=[1000], target_block_errors=3, target_BLER=1e-3, results_dir=str(tmp_path / "cut"), batch=8,
+                          simulate=lambda a, e, n, f: np.arange(f, f + n) % 4 != 1, max_points=3)
+    assert np.isnan(cut[1 / 3][0][1]) and next((tmp_path / "cut").iterdir()).read_text() == "1000\tNaN\n"
+    # MATLAB num2str in the file names
+    assert [H._num2str(v) for v in (1 / 3, 0.01, 1e-3, 0.5, 2, 1234.5, -1.5, 0.75)] == \
+        ["0.33333", "0.01", "0.001", "0.5", "2", "1234.5", "-1.5", "0.75"]
