@@ -162,7 +162,7 @@ def cfg5_strong_leg(torch, nrldpc, comm, args, world, rank, local_rank, dev, val
     kernel time (event pairs on the launch stream) is gathered so that the line carries a per-GPU figure.  Returns the
     leg's record on rank 0, None elsewhere."""
     total = args.cfg5_total
-    lo, hi = total * rank // world, total * (rank + 1) // world
+    lo, hi = importlib.import_module("ldpc-3gpp-matlab_amd.shard").shard_range(total, rank, world)
     n = hi - lo
     codec = nrldpc.Codec(BG, Z, max_iter=ITERS, n_layers=CFG5_LAYERS, early_term=True, llr_dtype=np.float16, device_id=local_rank)
     g = torch.Generator(device=dev)
@@ -496,7 +496,7 @@ def dry_run(args, torch):
     # the per-GPU bookkeeping of the cfg5_strong leg: a few numbers per rank
     leg = None
     if world > 1:
-        lo, hi = args.cfg5_total * rank // world, args.cfg5_total * (rank + 1) // world
+        lo, hi = importlib.import_module("ldpc-3gpp-matlab_amd.shard").shard_range(args.cfg5_total, rank, world)
         comm.barrier()
         t0 = time.perf_counter()
         time.sleep(0.001 * (rank + 1))

@@ -19,6 +19,7 @@ import numpy as np
 from ._capi import UnsupportedParameters
 from .decoder import NRLDPCDecoder
 from .encoder import NRLDPCEncoder
+from .shard import shard_range
 
 Q_M = {"BPSK": 1, "QPSK": 2, "16QAM": 4, "64QAM": 6, "256QAM": 8}
 
@@ -163,7 +164,7 @@ def simulate_point_device(chains, Q_m, EsN0, rv_id_sequence, batch, seed, first_
     import torch
     from ._capi import awgn_llr_dev
     D = len(chains)
-    cuts = [batch * i // D for i in range(D + 1)]
+    cuts = [shard_range(batch, d, D)[0] for d in range(D)] + [batch]   # contiguous slices (shard.py), as every multi-GPU path here
     N0 = 1.0 / 10.0 ** (EsN0 / 10.0)
     st = []
     for d, (enc_chain, dec_chain) in enumerate(chains):
