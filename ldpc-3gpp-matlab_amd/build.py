@@ -19,8 +19,11 @@ AB = bool(os.environ.get("NRLDPC_BUILD_AB"))
 # iterations, parity stop with all rows, parity stop with pruned rows) -- what tools/ab_ilv.py measures the list's mode bits from;
 # its own library and object directory (seed the directory with a copy of build/: only the changed units recompile)
 ALLMODES = bool(os.environ.get("NRLDPC_BUILD_ALLMODES"))
-LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip_ab.so" if AB else "libnrldpc_hip_allmodes.so" if ALLMODES else "libnrldpc_hip.so")  # env override: kernel experiments
-OBJDIR = os.path.join(HERE, "build_ab" if AB else "build_allmodes" if ALLMODES else "build")
+# NRLDPC_BUILD_EXTRA_FLAGS="<flags>": the experiment build with extra compiler flags for every unit (e.g. LLVM scheduling options), into its
+# own library and object directory (libnrldpc_hip_x.so, build_x/); load it with NRLDPC_LIB=<path>
+XFLAGS = os.environ.get("NRLDPC_BUILD_EXTRA_FLAGS", "").split()
+LIB = os.environ.get("NRLDPC_LIB") or os.path.join(HERE, "libnrldpc_hip_ab.so" if AB else "libnrldpc_hip_allmodes.so" if ALLMODES else "libnrldpc_hip_x.so" if XFLAGS else "libnrldpc_hip.so")  # env override: kernel experiments
+OBJDIR = os.path.join(HERE, "build_ab" if AB else "build_allmodes" if ALLMODES else "build_x" if XFLAGS else "build")
 SOURCES = ["nrldpc_decode.hip", "nrldpc_encode.hip", "nrldpc_ratematch.hip", "nrldpc_crc.hip", "nrldpc_channel.hip",
            "nrldpc_expand.hip", "nrldpc_capi.hip", "nrldpc_host_quant.cpp"]  # .cpp: host-only C++ (no device pass)
 Z64_SOURCE = "nrldpc_decode_z64_inst.hip"
@@ -53,7 +56,14 @@ Z64I = [
 # = NRLDPC_Z64_NL_LIST: (BG, Z, active layers) with pipelined kernels of their own
 Z64_NL = [(1, 384, 5), (1, 384, 13), (1, 384, 24), (2, 384, 32), (2, 384, 22), (2, 384, 17), (2, 384, 12), (2, 384, 9), (2, 384, 7), (2, 208, 21)]
 HEADERS = ["nrldpc_kernels.h", "nrldpc_dispatch_lists.h", "nrldpc_sched.h", "nrldpc_device.h", "nrldpc_decode_z64.h", "nrldpc_decode_z64s.h", "nrldpc_decode_z64p.h", "nrldpc_wave.h", "nrldpc_host_quant.h", "nrldpc_hostpath.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DNRLDPC_Z64_AB"] if AB else [])
+# -mllvm -enable-post-misched=false: LLVM's post-register-allocation machine scheduler off.  The decoder loops are VALU-issue bound and
+# hand-ordered (pinned read batches, s_setprio windows, launder() fences); the pre-RA scheduler keeps that order, the post-RA pass
+# reshuffles it for latencies the other waves of the CU already hide.  Measured on the MI355X over every lifting size, whole library
+# built both ways, order-balanced (profiles/r06_post_ra_scheduler_off.txt): 25 fixed iterations BG1 -3.0 % of the time (geometric mean;
+# 44 of 51 sizes by more than 2 %, the headline -2.1 %), BG2 -1.3 %; parity stop at the waterfall BG1 -1.5 %, BG2 -3.2 %; no size more than
+# 1.6 % slower.  Seven other scheduling options (max-ilp, max-memory-clause, iterative-ilp, AMDGPU trackers, metric bias, no clustering,
+# pre-RA direction) were within noise or worse.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-enable-post-misched=false"] + (["-DNRLDPC_Z64_AB"] if AB else []) + XFLAGS
 
 
 def _hipcc():
@@ -179,7 +189,7 @@ def build_lib(force=False, verbose=False, jobs=None):
 
     def compile_one(u):
         src, obj, defs = u
-        flags = [f for f in FLAGS if not f.startswith("--offload-arch")] if src.endswith(".cpp") else FLAGS
+        flags = [f for f in FLAGS if not f.startswith("--offload-arch") and f not in ("-mllvm", "-enable-post-misched=false")] if src.endswith(".cpp") else FLAGS  # host-only C++: no device pass, the compiler's own schedule
         uid = unit_id(src, flags, defs)
         try:
             with open(obj + ".id") as f:
