@@ -72,7 +72,10 @@ def main():
     tab = rates()
     with tempfile.TemporaryDirectory() as td:
         co = os.path.join(td, "k.co")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+        import importlib
+        sys.path.insert(0, ROOT)
+        flags = [f for f in importlib.import_module("ldpc-3gpp-matlab_amd.build").FLAGS if f != "-fPIC"]  # the library's own flags (scheduling options included)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-I" + os.path.join(ROOT, "include"),
                                "-I" + CSRC, "-DNRLDPC_Z64_BG=%d" % a.bg, "-DNRLDPC_Z64_Z=%d" % a.z, "--cuda-device-only",
                                "--no-gpu-bundle-output", "-c", os.path.join(CSRC, "nrldpc_decode_z64_inst.hip"), "-o", co])
         dis = subprocess.check_output([OBJDUMP, "-d", co], text=True)
