@@ -9,6 +9,8 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("ldpc-3gpp-matlab_amd")
 DIMS = {1: (46, 68, 22), 2: (42, 52, 10)}
 ALL_Z = sorted(a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384)
+if os.environ.get("ALLZ_ONLY"):  # a subset of the lifting sizes (A/B sessions)
+    ALL_Z = [z for z in ALL_Z if z in {int(x) for x in os.environ["ALLZ_ONLY"].split(",")}]
 out = []
 for bg in (() if os.environ.get("STOP") else (1, 2)):
     rows, cols, kb = DIMS[bg]
