@@ -11,7 +11,7 @@ NEW=""
 for u in "$@"; do
   BG=${u%,*}; Z=${u#*,}
   O=$R/exp_libs/z64_${NAME}_${BG}_${Z}.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -I$P/csrc -DNRLDPC_Z64_BG=$BG -DNRLDPC_Z64_Z=$Z -DNRLDPC_UNIT=u_z64_${BG}_${Z} $EXTRA -c $P/csrc/nrldpc_decode_z64_inst.hip -o $O &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -enable-post-misched=false -I$R/include -I$P/csrc -DNRLDPC_Z64_BG=$BG -DNRLDPC_Z64_Z=$Z -DNRLDPC_UNIT=u_z64_${BG}_${Z} $EXTRA -c $P/csrc/nrldpc_decode_z64_inst.hip -o $O &
   OBJS=$(echo "$OBJS" | grep -v "/z64_${BG}_${Z}.o")
   NEW="$NEW $O"
 done

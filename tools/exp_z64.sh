@@ -12,10 +12,10 @@ TAG=${BG}_${Z}${NL:+_nl$NL}
 NAME=${TAG}_${N}_${W}${SUFFIX:+_$SUFFIX}
 O=$R/exp_libs/z64_${NAME}.o
 if [ -n "$PACKED" ]; then
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -I$P/csrc -DNRLDPC_Z64_BG=$BG -DNRLDPC_Z64_Z=$Z $EXTRA -c $P/csrc/nrldpc_decode_z64p_inst.hip -o $O
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -enable-post-misched=false -I$R/include -I$P/csrc -DNRLDPC_Z64_BG=$BG -DNRLDPC_Z64_Z=$Z $EXTRA -c $P/csrc/nrldpc_decode_z64p_inst.hip -o $O
 OBJS=$(ls $P/build/*.o | grep -v "z64p_${TAG}.o")
 else
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -I$P/csrc -DNRLDPC_Z64_BG=$BG -DNRLDPC_Z64_Z=$Z ${NL:+-DNRLDPC_Z64_NL=$NL} -DNRLDPC_Z64_NCWG=$N -DNRLDPC_Z64_WPE=$W $EXTRA -c $P/csrc/nrldpc_decode_z64_inst.hip -o $O
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -enable-post-misched=false -I$R/include -I$P/csrc -DNRLDPC_Z64_BG=$BG -DNRLDPC_Z64_Z=$Z ${NL:+-DNRLDPC_Z64_NL=$NL} -DNRLDPC_Z64_NCWG=$N -DNRLDPC_Z64_WPE=$W $EXTRA -c $P/csrc/nrldpc_decode_z64_inst.hip -o $O
 OBJS=$(ls $P/build/*.o | grep -v "z64_${TAG}.o")
 fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $O -o $R/exp_libs/lib_${NAME}.so
